@@ -1,0 +1,222 @@
+/* rt_abi.h — C ABI of librt_mi355x.so, the MI355X (gfx950) path-tracing backend that replaces the BODY of
+ * the reference's `Camera::render` (reference: src/camera/mod.rs:54-117) and everything it calls.
+ *
+ * The reference (arnfaldur/raytracer, Rust) has no FFI/plugin API of its own; the narrowest seam is the
+ * method `Camera::render(&self, world, sender)` (src/camera/mod.rs:54-58), reached through
+ * `Scene::render` (src/scene.rs:30-32).  A Rust `extern "C"` block binding exactly these entry points,
+ * plus the `describe()` flattening the host needs, is shown in INTEGRATION.md.  Each entry point below cites
+ * the reference interface it replaces.
+ *
+ * Conventions: plain C, POD structs, little-endian, no torch / C++ types.  Every function returns an
+ * rt_status (0 = OK, <0 = error) unless stated otherwise and never unwinds, throws or aborts across the
+ * boundary.  `rt_last_error(ctx)` returns a UTF-8 message owned by the ctx.  A ctx is bound to ONE GPU and
+ * is NOT thread-safe (one ctx per calling thread; the reference calls render from one dedicated thread,
+ * src/main.rs:50-58).  Multi-GPU = one process (or thread) + one ctx per GPU, each rendering a disjoint
+ * residue class of the per-pixel sample indices; the caller sums the partial frames (RCCL reduce).
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_E_INVALID_ARG = -1, /* reference: the expect()/panic! sites of builder.rs:58-72 */
+  RT_E_HIP = -2,         /* a hip* call failed (message carries hipGetErrorString) */
+  RT_E_OOM = -3,
+  RT_E_UNSUPPORTED = -4,
+  RT_E_INTERNAL = -5
+} rt_status;
+
+typedef struct rt_ctx rt_ctx;     /* one GPU: device id, stream, work buffers */
+typedef struct rt_scene rt_scene; /* device-resident flattened world (prims, BVH, materials, textures) */
+
+/* ---- world description (host side flattening of the Hittable tree) ------------------------------------
+ * Replaces: the `Box<dyn Hittable>` world handed to Camera::render (src/camera/mod.rs:56) — Sphere /
+ * MovingSphere (src/hittable/geometry.rs:12-17,84-87) inside HittableList / BVHNode
+ * (src/hittable/containers.rs:13-16,48-52).  Containers are NOT described: closest-hit semantics make
+ * the result independent of BVH topology (containers.rs:29-40,177-191), so the library builds its own
+ * acceleration structure from the flat primitive list. */
+typedef enum rt_prim_type {
+  RT_PRIM_SPHERE = 0,        /* geometry.rs:12-81: a=center, radius (negative allowed: flips the normal) */
+  RT_PRIM_MOVING_SPHERE = 1, /* geometry.rs:84-114: a=center at time 0, b=destination at time 1 */
+  RT_PRIM_QUAD = 2,          /* EXT (not in reference, SURVEY aX1): a=Q, b=u, c=v */
+  RT_PRIM_MEDIUM_SPHERE = 3, /* EXT (aX3): constant medium bounded by sphere a/radius, `density` */
+  RT_PRIM_MEDIUM_BOX = 4     /* EXT (aX3): constant medium bounded by the box a + s*b + t*c + w*d, s,t,w in [0,1] */
+} rt_prim_type;
+
+typedef struct rt_prim {
+  uint32_t type;        /* rt_prim_type */
+  uint32_t material_id; /* index into rt_scene_desc.materials */
+  int32_t object_id;    /* caller's id, reported by rt_intersect (insertion order of world.add) */
+  uint32_t reserved;
+  double a[3];
+  double b[3];
+  double c[3];
+  double d[3];
+  double radius;
+  double density;
+} rt_prim;
+
+typedef enum rt_material_kind {
+  RT_MAT_LAMBERTIAN = 0, /* materials.rs:14-16,28-43: albedo = texture `tex` */
+  RT_MAT_METAL = 1,      /* materials.rs:59-80: albedo rgb, fuzz */
+  RT_MAT_DIELECTRIC = 2, /* materials.rs:89-129: ior */
+  RT_MAT_DIFFUSE_LIGHT = 3, /* EXT (aX4): emits texture `tex`, never scatters */
+  RT_MAT_ISOTROPIC = 4      /* EXT (aX3): uniform phase function, albedo = texture `tex` */
+} rt_material_kind;
+
+typedef struct rt_material {
+  uint32_t kind; /* rt_material_kind */
+  int32_t tex;   /* texture index (LAMBERTIAN, DIFFUSE_LIGHT, ISOTROPIC) or -1 */
+  double albedo[3];
+  double fuzz;
+  double ior;
+} rt_material;
+
+typedef enum rt_texture_kind {
+  RT_TEX_SOLID = 0,   /* texture.rs:20-36 */
+  RT_TEX_CHECKER = 1, /* texture.rs:39-66: inv_scale, odd / even = child texture indices */
+  RT_TEX_IMAGE = 2,   /* texture.rs:69-93: RGBA8 texels at texel_offset (bytes) in the blob, width x height */
+  RT_TEX_NOISE = 3    /* texture.rs:96-154: inv_scale; grey Hermite lattice noise (noise_at variant) */
+} rt_texture_kind;
+
+typedef struct rt_texture {
+  uint32_t kind; /* rt_texture_kind */
+  int32_t odd;   /* CHECKER: texture used when (x+y+z) rem_euclid 2 == 0 (texture.rs:60-61) */
+  int32_t even;
+  uint32_t width, height; /* IMAGE */
+  uint32_t reserved;
+  uint64_t texel_offset; /* IMAGE: byte offset into rt_scene_desc.texels, RGBA8 row-major */
+  double rgb[3];         /* SOLID */
+  double inv_scale;      /* CHECKER, NOISE */
+} rt_texture;
+
+typedef struct rt_scene_desc {
+  const rt_prim* prims;
+  uint64_t n_prims;
+  const rt_material* materials;
+  uint64_t n_materials;
+  const rt_texture* textures;
+  uint64_t n_textures;
+  const uint8_t* texels; /* may be NULL when no IMAGE texture */
+  uint64_t n_texel_bytes;
+} rt_scene_desc;
+
+/* ---- camera block -------------------------------------------------------------------------------------
+ * Replaces: the private fields of `Camera` (src/camera/mod.rs:26-51) as derived by
+ * CameraBuilder::build (src/camera/builder.rs:84-107). */
+typedef enum rt_sampler_kind {
+  RT_SAMPLER_UNIFORM = 0, /* PixelSampler::Uniform(n): n x n fixed grid, no jitter (mod.rs:150-163) */
+  RT_SAMPLER_RANDOM = 1   /* PixelSampler::Random(n): n jittered samples (mod.rs:164-172) */
+} rt_sampler_kind;
+
+typedef struct rt_camera {
+  uint32_t width, height;
+  uint32_t sampler_kind; /* rt_sampler_kind */
+  uint32_t sampler_n;    /* grid side (UNIFORM, spp = n*n) or sample count (RANDOM, spp = n) */
+  uint32_t max_depth;    /* `depth` (mod.rs:30): rays at depth >= max_depth return black (mod.rs:195-197) */
+  uint32_t background_mode; /* 0 = sky gradient of mod.rs:205-207 (reference), 1 = solid `background` (EXT aX4) */
+  double center[3];
+  double pixel00[3];
+  double du[3], dv[3];               /* pixel_delta_u / pixel_delta_v */
+  double defocus_u[3], defocus_v[3]; /* defocus_disk_u / defocus_disk_v */
+  double defocus_angle;              /* <= 0: pinhole (mod.rs:178) */
+  double background[3];
+} rt_camera;
+
+/* ---- parity probe records ----------------------------------------------------------------------------- */
+typedef struct rt_ray {
+  double o[3], d[3], time; /* src/ray.rs:7-11 */
+} rt_ray;
+typedef struct rt_hit { /* src/hittable/mod.rs:31-39 (material replaced by object_id) */
+  int32_t object_id;    /* -1 = miss */
+  int32_t front_face;
+  double t;
+  double p[3];
+  double n[3];
+  double u, v;
+} rt_hit;
+
+typedef struct rt_stats {
+  uint64_t paths;          /* samples rendered by the last rt_render* call */
+  uint64_t rays;           /* rays traced (all bounces) */
+  uint32_t passes;         /* sample batches the render was split into */
+  uint32_t bounces_run;    /* bounce iterations launched */
+  float ms_total;          /* hipEvent time of the whole render on the library's stream */
+  float ms_generate, ms_intersect, ms_shade, ms_accumulate; /* per stage (only when profiling is enabled) */
+  uint64_t intersect_launches;
+} rt_stats;
+
+/* ---- entry points --------------------------------------------------------------------------------------*/
+
+/* Create a context on HIP device `device_id`.  No reference counterpart (the reference is CPU-only; the
+ * closest analogue is thread::available_parallelism() at src/camera/mod.rs:63). */
+int rt_init(int device_id, rt_ctx** out);
+int rt_shutdown(rt_ctx* ctx);
+/* Message of the last failing call on this ctx ("" if none).  rt_last_error(NULL) returns the message of the
+ * last failing rt_init. */
+const char* rt_last_error(rt_ctx* ctx);
+int rt_abi_version(void);
+
+/* Upload a flattened world: validates it, builds the acceleration structure (SAH BVH2, host) and copies
+ * everything into HBM.  The library copies; the caller keeps ownership of every pointer in `desc`.
+ * Replaces: HittableList::into_bvh / BVHNode::from_vec (src/hittable/containers.rs:23-25,54-152). */
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out);
+int rt_scene_free(rt_ctx* ctx, rt_scene* scene);
+
+/* Closest hit of `n` host rays over t in (1e-6, inf), exclusive (src/camera/mod.rs:198).
+ * Replaces: `world.hit(ray, &(0.000001..f64::INFINITY))` = Hittable::hit (src/hittable/mod.rs:27) through
+ * BVHNode::hit / HittableList::hit / Sphere::calculate_hit / MovingSphere::hit.  Parity probe. */
+int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_t n, rt_hit* out_hits);
+
+/* Render samples {s = sample_begin + k*sample_stride < sample_end} of every pixel and write the
+ * UN-NORMALISED linear RGB sums (row-major, W*H*3 f32) to `out_sum`.  For the UNIFORM sampler s enumerates the
+ * grid cells (yi, xi) = (s / n, s % n); for RANDOM s = 0..n-1.  `seed` keys the counter-based RNG
+ * (Philox4x32-10, counter = pixel, sample, bounce, purpose), so the sum over any partition of the sample
+ * indices equals the single-call result up to f32 summation order.
+ * Replaces: the body of Camera::render / render_rect / sample_pixel / sample_point / ray_color
+ * (src/camera/mod.rs:54-214).  rt_render takes a HOST output pointer (blocking; includes the D2H copy);
+ * rt_render_device takes a DEVICE pointer and a hipStream_t (NULL = the ctx's stream) and is asynchronous
+ * with respect to the host. */
+int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+              uint32_t sample_end, uint32_t sample_stride, float* out_sum);
+int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+                     uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream);
+
+/* mean = sum / spp, gamma correction powf(1/gamma) per channel, optional 8-bit quantisation
+ * `(256.0 * x) as u8` (saturating, NaN -> 0).  Either output may be NULL.  Host pointers.
+ * Replaces: `accumulator / n` (mod.rs:162,171), Color::gamma_corrected (src/color.rs:58-61, gamma 2.2 at
+ * mod.rs:134) and Color::into_u8 (src/color.rs:68-73).  `out_rgb` is what the reference's tile messages
+ * carry (gamma-corrected f64, row-major). */
+int rt_resolve(rt_ctx* ctx, const float* sum, uint32_t width, uint32_t height, uint32_t spp, double gamma,
+               double* out_rgb, uint8_t* out_rgb8);
+/* Same on device pointers (f32 sum in, f64 / u8 out), asynchronous on `hip_stream` (NULL = ctx stream). */
+int rt_resolve_device(rt_ctx* ctx, const float* d_sum, uint32_t width, uint32_t height, uint32_t spp, double gamma,
+                      double* d_out_rgb, uint8_t* d_out_rgb8, void* hip_stream);
+
+/* Counters / timings of the last render on this ctx.  Replaces: the wall-clock print of src/main.rs:51-57. */
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/* Tunables: "max_paths" (paths in flight per pass), "profile" (1 = per-stage hipEvent timing, serialises
+ * stages), "mode" (0 = wavefront kernels, 1 = fused persistent kernel), "bin_materials" (0/1).
+ * Unknown keys return RT_E_INVALID_ARG.  No reference counterpart (constants are edited in main.rs:28-43). */
+int rt_set_option(rt_ctx* ctx, const char* key, int64_t value);
+
+/* Host-side reference implementation of the counter-based generator used on the device (Philox4x32-10),
+ * exported so tests can check it against the published Random123 known-answer vectors. */
+void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* Synchronise the ctx's stream (for callers of the *_device entry points). */
+int rt_synchronize(rt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

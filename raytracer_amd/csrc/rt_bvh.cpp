@@ -1,0 +1,173 @@
+// rt_bvh.cpp — binned-SAH BVH2 builder (host).  See rt_bvh.h.
+#include "rt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+
+namespace rtb {
+namespace {
+
+const double INF = std::numeric_limits<double>::infinity();
+
+struct Builder {
+  const std::vector<Box>& boxes;
+  std::vector<uint32_t> idx;
+  std::vector<FlatNode> nodes;
+  int max_depth;
+  int depth_seen = 0;
+
+  Builder(const std::vector<Box>& b, int md) : boxes(b), idx(b.size()), max_depth(md) {
+    std::iota(idx.begin(), idx.end(), 0u);
+  }
+
+  static Box empty_box() {
+    Box b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = INF; b.hi[a] = -INF; }
+    return b;
+  }
+  static void grow(Box& b, const Box& o) {
+    for (int a = 0; a < 3; a++) { b.lo[a] = std::fmin(b.lo[a], o.lo[a]); b.hi[a] = std::fmax(b.hi[a], o.hi[a]); }
+  }
+  static double area(const Box& b) {
+    double dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+  double centroid(uint32_t i, int a) const { return 0.5 * (boxes[i].lo[a] + boxes[i].hi[a]); }
+
+  // conservative f32 image of an f64 box: pad by 2^-20 relative to the coordinate magnitude (covers the f32
+  // rounding of the plane itself and of plane*inv in the slab test), then round outward.
+  static float down(double v) {
+    double p = v - (std::fabs(v) * 9.5367431640625e-07 + 1e-30);
+    float f = (float)p;
+    if ((double)f > p) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+  }
+  static float up(double v) {
+    double p = v + (std::fabs(v) * 9.5367431640625e-07 + 1e-30);
+    float f = (float)p;
+    if ((double)f < p) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+  }
+  static void store(const Box& b, float* lo, float* hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = down(b.lo[a]); hi[a] = up(b.hi[a]); }
+  }
+
+  // builds idx[begin,end); returns child reference and its bounds
+  int32_t build(size_t begin, size_t end, int depth, Box& out_box) {
+    depth_seen = std::max(depth_seen, depth);
+    size_t n = end - begin;
+    if (n == 1) {
+      out_box = boxes[idx[begin]];
+      return ~(int32_t)idx[begin];
+    }
+    Box cb = empty_box();
+    for (size_t i = begin; i < end; i++)
+      for (int a = 0; a < 3; a++) {
+        double c = centroid(idx[i], a);
+        cb.lo[a] = std::fmin(cb.lo[a], c);
+        cb.hi[a] = std::fmax(cb.hi[a], c);
+      }
+    size_t mid = begin + n / 2;
+    bool split_done = false;
+    // depth budget: a balanced median split of n items needs ceil(log2 n) levels
+    int need = 0;
+    while (((size_t)1 << need) < n) need++;
+    bool force_median = depth + need + 1 >= max_depth;
+    if (!force_median) {
+      const int NB = 32;
+      double best_cost = INF;
+      int best_axis = -1, best_bin = -1;
+      for (int a = 0; a < 3; a++) {
+        double ext = cb.hi[a] - cb.lo[a];
+        if (!(ext > 0)) continue;
+        Box bb[NB];
+        size_t cnt[NB];
+        for (int b = 0; b < NB; b++) { bb[b] = empty_box(); cnt[b] = 0; }
+        double scale = NB / ext;
+        for (size_t i = begin; i < end; i++) {
+          int b = (int)((centroid(idx[i], a) - cb.lo[a]) * scale);
+          b = std::min(std::max(b, 0), NB - 1);
+          grow(bb[b], boxes[idx[i]]);
+          cnt[b]++;
+        }
+        double ra[NB];
+        size_t rc[NB];
+        Box acc = empty_box();
+        size_t c = 0;
+        for (int b = NB - 1; b > 0; b--) {
+          grow(acc, bb[b]);
+          c += cnt[b];
+          ra[b] = area(acc);
+          rc[b] = c;
+        }
+        acc = empty_box();
+        c = 0;
+        for (int b = 0; b < NB - 1; b++) {
+          grow(acc, bb[b]);
+          c += cnt[b];
+          if (c == 0 || rc[b + 1] == 0) continue;
+          double cost = area(acc) * (double)c + ra[b + 1] * (double)rc[b + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+        }
+      }
+      if (best_axis >= 0) {
+        int a = best_axis;
+        double ext = cb.hi[a] - cb.lo[a];
+        double scale = 32 / ext;
+        auto it = std::partition(idx.begin() + begin, idx.begin() + end, [&](uint32_t i) {
+          int b = (int)((centroid(i, a) - cb.lo[a]) * scale);
+          b = std::min(std::max(b, 0), 31);
+          return b <= best_bin;
+        });
+        size_t m = (size_t)(it - idx.begin());
+        if (m > begin && m < end) { mid = m; split_done = true; }
+      }
+    }
+    if (!split_done) {
+      // median split along the widest centroid axis (or index order if all centroids coincide)
+      int a = 0;
+      double best = -1;
+      for (int k = 0; k < 3; k++) {
+        double e = cb.hi[k] - cb.lo[k];
+        if (e > best) { best = e; a = k; }
+      }
+      mid = begin + n / 2;
+      if (best > 0)
+        std::nth_element(idx.begin() + begin, idx.begin() + mid, idx.begin() + end,
+                         [&](uint32_t x, uint32_t y) { return centroid(x, a) < centroid(y, a); });
+    }
+    int32_t me = (int32_t)nodes.size();
+    nodes.emplace_back();
+    Box lb, rb;
+    int32_t l = build(begin, mid, depth + 1, lb);
+    int32_t r = build(mid, end, depth + 1, rb);
+    FlatNode& nd = nodes[(size_t)me];
+    store(lb, nd.l_lo, nd.l_hi);
+    store(rb, nd.r_lo, nd.r_hi);
+    nd.left = l;
+    nd.right = r;
+    nd.pad[0] = nd.pad[1] = 0;
+    out_box = lb;
+    grow(out_box, rb);
+    return me;
+  }
+};
+
+}  // namespace
+
+BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth) {
+  BuildResult res;
+  if (boxes.empty()) return res;
+  Builder b(boxes, max_depth);
+  b.nodes.reserve(boxes.size());
+  Box root_box;
+  res.root = b.build(0, boxes.size(), 0, root_box);
+  res.nodes = std::move(b.nodes);
+  res.depth = b.depth_seen;
+  return res;
+}
+
+}  // namespace rtb

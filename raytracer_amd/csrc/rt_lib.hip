@@ -1,0 +1,803 @@
+// rt_lib.hip — librt_mi355x.so: HIP kernels (gfx950) + the C ABI of include/rt_abi.h.
+//
+// Wavefront pipeline replacing the body of Camera::render (reference src/camera/mod.rs:54-214):
+//   k_generate   sample_pixel + sample_point            (mod.rs:143-186, 211-214)
+//   k_intersect  world.hit: BVH traversal, LDS stack    (containers.rs:177-191, aabb.rs:48-71, geometry.rs:36-71)
+//   k_shade      ray_color_inner body: scatter / sky    (mod.rs:195-207, materials.rs, texture.rs)
+//                + wave64 ballot/prefix compaction of surviving rays into the next queue
+//   k_accumulate accumulator += sample                  (mod.rs:159,169)
+//   k_resolve    / n, gamma, into_u8                    (mod.rs:162,171,134; color.rs:58-73)
+// All queues live in HBM as structure-of-arrays; every path of a pass is in flight at once.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_bvh.h"
+#include "rt_device.h"
+
+using namespace rtd;
+
+// ================================================================================================ kernels
+
+struct PassParams {
+  uint32_t n_paths;  // paths in this pass = n_pix_pass * S
+  uint32_t pix0;     // first pixel of the pass
+  uint32_t S;        // samples per pixel in this pass
+  uint32_t s_first;  // sample index of k = 0
+  uint32_t s_stride;
+  uint32_t k0, k1;  // Philox key (seed)
+};
+
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(Camera cam, Queue q, float* __restrict__ Lr,
+                                                       float* __restrict__ Lg, float* __restrict__ Lb, PassParams pp,
+                                                       uint32_t* __restrict__ counts) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < pp.n_paths; i += stride) {
+    uint32_t pl = i / pp.S, k = i - pl * pp.S;
+    uint32_t pixel = pp.pix0 + pl, s = pp.s_first + k * pp.s_stride;
+    d3 o, d;
+    double time;
+    generate_ray(cam, pixel, s, pp.k0, pp.k1, o, d, time);
+    q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
+    q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
+    q.time[i] = time;
+    q.tr[i] = 1.f; q.tg[i] = 1.f; q.tb[i] = 1.f;
+    q.id[i] = i;
+    Lr[i] = 0.f; Lg[i] = 0.f; Lb[i] = 0.f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = pp.n_paths;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect(Scene sc, Queue q, Hits h, const uint32_t* __restrict__ count) {
+  __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+  const uint32_t n = *count;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    d3 o = {q.ox[i], q.oy[i], q.oz[i]}, d = {q.dx[i], q.dy[i], q.dz[i]};
+    HitInfo hit = traverse(sc, o, d, q.time[i], RT_TMIN, stack + threadIdx.x, RT_BLOCK);
+    h.prim[i] = hit.prim;
+    h.t[i] = hit.t;
+  }
+}
+
+// wave64 compaction: ballot -> exclusive prefix via mbcnt -> one atomic per wave
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+  unsigned long long mask = __ballot(pred);
+  uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  uint32_t total = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  if (total) {
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, total);
+    base = __shfl(base, leader, 64);
+  }
+  return base + lane_prefix;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue qi, Hits h, Queue qo,
+                                                    const uint32_t* __restrict__ count_in,
+                                                    uint32_t* __restrict__ count_out, float* __restrict__ Lr,
+                                                    float* __restrict__ Lg, float* __restrict__ Lb, PassParams pp,
+                                                    uint32_t bounce, uint32_t last_bounce) {
+  const uint32_t n = *count_in;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  // wave-uniform trip count: every lane of a wave reaches the ballot
+  for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+    const uint32_t i = base + (threadIdx.x & 63u);
+    bool alive = false;
+    ShadeOut so;
+    uint32_t id = 0;
+    double time = 0;
+    if (i < n) {
+      d3 o = {qi.ox[i], qi.oy[i], qi.oz[i]}, d = {qi.dx[i], qi.dy[i], qi.dz[i]};
+      time = qi.time[i];
+      f3 thr = {qi.tr[i], qi.tg[i], qi.tb[i]};
+      id = qi.id[i];
+      HitInfo hit;
+      hit.prim = h.prim[i];
+      hit.t = h.t[i];
+      uint32_t pl = id / pp.S, k = id - pl * pp.S;
+      uint32_t pixel = pp.pix0 + pl, s = pp.s_first + k * pp.s_stride;
+      so = shade(sc, cam, o, d, time, thr, hit, pixel, s, bounce, pp.k0, pp.k1);
+      if (so.terminated) {
+        Lr[id] = so.radiance.x; Lg[id] = so.radiance.y; Lb[id] = so.radiance.z;
+      }
+      // a ray scattered at the last allowed depth returns black (mod.rs:195-197): drop it, L stays 0
+      alive = so.alive && !last_bounce;
+    }
+    uint32_t slot = wave_append(alive, count_out);
+    if (alive) {
+      qo.ox[slot] = so.o.x; qo.oy[slot] = so.o.y; qo.oz[slot] = so.o.z;
+      qo.dx[slot] = so.d.x; qo.dy[slot] = so.d.y; qo.dz[slot] = so.d.z;
+      qo.time[slot] = time;
+      qo.tr[slot] = so.thr.x; qo.tg[slot] = so.thr.y; qo.tb[slot] = so.thr.z;
+      qo.id[slot] = id;
+    }
+  }
+}
+
+// fb[pixel] += sum_k L[pl*S + k]; also tallies the rays traced (sum of the per-bounce queue counts)
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float* __restrict__ Lr, const float* __restrict__ Lg,
+                                                         const float* __restrict__ Lb, float* __restrict__ fb,
+                                                         PassParams pp, uint32_t n_pix_pass,
+                                                         const uint32_t* __restrict__ counts, uint32_t n_counts,
+                                                         unsigned long long* __restrict__ ray_total) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x; pl < n_pix_pass; pl += stride) {
+    float r = 0.f, g = 0.f, b = 0.f;
+    const size_t base = (size_t)pl * pp.S;
+    for (uint32_t k = 0; k < pp.S; k++) {
+      r += Lr[base + k]; g += Lg[base + k]; b += Lb[base + k];
+    }
+    const size_t p = (size_t)(pp.pix0 + pl) * 3;
+    fb[p] += r; fb[p + 1] += g; fb[p + 2] += b;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (uint32_t i = 0; i < n_counts; i++) t += counts[i];
+    *ray_total += t;
+  }
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ sum, uint32_t n_values, double inv_spp,
+                                                      double inv_gamma, double* __restrict__ out_rgb,
+                                                      uint8_t* __restrict__ out_u8) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
+    double v = pow((double)sum[i] * inv_spp, inv_gamma);  // color.rs:58-61
+    if (out_rgb) out_rgb[i] = v;
+    if (out_u8) {  // color.rs:68-73: (256.0 * x) as u8 — saturating, NaN -> 0
+      double x = 256.0 * v;
+      uint8_t q = 0;
+      if (x == x) q = x <= 0.0 ? 0 : (x >= 255.0 ? 255 : (uint8_t)x);
+      out_u8[i] = q;
+    }
+  }
+}
+
+// parity probe: closest hit + full hit record for caller-supplied f64 rays
+__global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, const rt_ray* __restrict__ rays, uint32_t n,
+                                                    rt_hit* __restrict__ out) {
+  __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    rt_ray r = rays[i];
+    d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
+    HitInfo hit = traverse(sc, o, d, r.time, RT_TMIN, stack + threadIdx.x, RT_BLOCK);
+    rt_hit ho;
+    memset(&ho, 0, sizeof(ho));
+    ho.object_id = -1;
+    if (hit.prim >= 0) {
+      const Prim& P = sc.prims[hit.prim];
+      HitRec h = make_hit(P, o, d, r.time, hit.t, true);
+      ho.object_id = P.obj;
+      ho.front_face = h.front ? 1 : 0;
+      ho.t = hit.t;
+      ho.p[0] = h.p.x; ho.p[1] = h.p.y; ho.p[2] = h.p.z;
+      ho.n[0] = h.n.x; ho.n[1] = h.n.y; ho.n[2] = h.n.z;
+      ho.u = h.u; ho.v = h.v;
+    }
+    out[i] = ho;
+  }
+}
+
+// ================================================================================================ host side
+
+struct rt_scene {
+  BvhNode* d_nodes = nullptr;
+  Prim* d_prims = nullptr;
+  Material* d_mats = nullptr;
+  Texture* d_texs = nullptr;
+  uint32_t* d_texels = nullptr;
+  Scene view{};
+  int bvh_depth = 0;
+};
+
+struct WorkBuffers {
+  size_t cap = 0;
+  void* slab = nullptr;  // one allocation holding both queues, hits and L
+  Queue q[2]{};
+  Hits hits{};
+  float *Lr = nullptr, *Lg = nullptr, *Lb = nullptr;
+};
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int64_t max_paths = 32ll << 20;
+  int profile = 0;
+  int mode = 0;
+  WorkBuffers wb;
+  uint32_t* d_counts = nullptr;
+  size_t counts_cap = 0;
+  unsigned long long* d_ray_total = nullptr;
+  uint4* d_noise_table = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr;
+  bool timing_pending = false;
+  rt_stats stats{};
+  int n_cu = 256;
+};
+
+static std::string g_init_err;
+
+#define HIP_TRY(ctx, call)                                                                                   \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess) {                                                                                  \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                        \
+      return e_ == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP;                                                \
+    }                                                                                                        \
+  } while (0)
+
+static int fail(rt_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  else g_init_err = msg;
+  return code;
+}
+
+// xoroshiro128+ short jump (reference src/random.rs:18-28,37-57) — used only to tabulate the jump's GF(2)
+// matrix for the noise texture's lattice hash (src/hittable/texture.rs:148-154).
+static void xoro_short_jump(uint64_t s[2]) {
+  static const uint64_t J[2] = {0xdf900294d8f554a5ULL, 0x170865df4b3201fcULL};
+  uint64_t s0 = 0, s1 = 0;
+  for (int w = 0; w < 2; w++)
+    for (int b = 0; b < 64; b++) {
+      if (J[w] & (1ULL << b)) { s0 ^= s[0]; s1 ^= s[1]; }
+      uint64_t a = s[0], c = s[1] ^ s[0];
+      s[0] = ((a << 24) | (a >> 40)) ^ c ^ (c << 16);
+      s[1] = (c << 37) | (c >> 27);
+    }
+  s[0] = s0;
+  s[1] = s1;
+}
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+int rt_init(int device_id, rt_ctx** out) {
+  if (!out) return fail(nullptr, RT_E_INVALID_ARG, "rt_init: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, RT_E_HIP, std::string("rt_init: no HIP device available: ") + hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(nullptr, RT_E_INVALID_ARG, "rt_init: device_id out of range");
+  rt_ctx* ctx = new (std::nothrow) rt_ctx();
+  if (!ctx) return fail(nullptr, RT_E_OOM, "rt_init: out of host memory");
+  ctx->device = device_id;
+  auto bail = [&](const char* what, hipError_t err) {
+    g_init_err = std::string("rt_init: ") + what + ": " + hipGetErrorString(err);
+    delete ctx;
+    return (int)RT_E_HIP;
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+  ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc(&ctx->d_ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  // noise jump table: entry [byte position i][value v] = short_jump(state with only that byte set)
+  std::vector<uint32_t> tab(16 * 256 * 4);
+  for (int i = 0; i < 16; i++)
+    for (int v = 0; v < 256; v++) {
+      uint64_t s[2] = {0, 0};
+      s[i / 8] = (uint64_t)v << (8 * (i % 8));
+      xoro_short_jump(s);
+      uint32_t* t = &tab[(size_t)(i * 256 + v) * 4];
+      t[0] = (uint32_t)s[0]; t[1] = (uint32_t)(s[0] >> 32); t[2] = (uint32_t)s[1]; t[3] = (uint32_t)(s[1] >> 32);
+    }
+  if ((e = hipMalloc(&ctx->d_noise_table, tab.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemcpy(ctx->d_noise_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+    return bail("hipMemcpy", e);
+  *out = ctx;
+  return RT_OK;
+}
+
+static void free_work(rt_ctx* ctx) {
+  if (ctx->wb.slab) (void)hipFree(ctx->wb.slab);
+  ctx->wb = WorkBuffers();
+}
+
+int rt_shutdown(rt_ctx* ctx) {
+  if (!ctx) return RT_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_work(ctx);
+  if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+  if (ctx->d_ray_total) (void)hipFree(ctx->d_ray_total);
+  if (ctx->d_noise_table) (void)hipFree(ctx->d_noise_table);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
+  if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return RT_OK;
+}
+
+int rt_synchronize(rt_ctx* ctx) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return RT_E_INVALID_ARG;
+  std::string k(key);
+  if (k == "max_paths") {
+    if (value < 64 || value > (int64_t)0xFFFFFFFFll - 4096) return fail(ctx, RT_E_INVALID_ARG, "max_paths out of range");
+    ctx->max_paths = value;
+  } else if (k == "profile") {
+    ctx->profile = value ? 1 : 0;
+  } else if (k == "mode") {
+    if (value != 0) return fail(ctx, RT_E_UNSUPPORTED, "mode: only 0 (wavefront) is implemented");
+    ctx->mode = (int)value;
+  } else {
+    return fail(ctx, RT_E_INVALID_ARG, "rt_set_option: unknown key " + k);
+  }
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ scene upload
+static bool finite3(const double* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+static int validate_texture_graph(rt_ctx* ctx, const rt_scene_desc* d) {
+  for (uint64_t i = 0; i < d->n_textures; i++) {
+    const rt_texture& t = d->textures[i];
+    if (t.kind > RT_TEX_NOISE) return fail(ctx, RT_E_INVALID_ARG, "texture " + std::to_string(i) + ": unknown kind");
+    if (t.kind == RT_TEX_CHECKER) {
+      if (t.odd < 0 || (uint64_t)t.odd >= d->n_textures || t.even < 0 || (uint64_t)t.even >= d->n_textures)
+        return fail(ctx, RT_E_INVALID_ARG, "texture " + std::to_string(i) + ": checker child out of range");
+      // children must come earlier in the table (acyclic, bounded nesting)
+      if ((uint64_t)t.odd >= i || (uint64_t)t.even >= i)
+        return fail(ctx, RT_E_INVALID_ARG, "texture " + std::to_string(i) + ": checker children must precede it");
+    }
+    if (t.kind == RT_TEX_IMAGE) {
+      uint64_t bytes = (uint64_t)t.width * t.height * 4;
+      if ((t.texel_offset & 3) || t.texel_offset + bytes > d->n_texel_bytes || (bytes && !d->texels))
+        return fail(ctx, RT_E_INVALID_ARG, "texture " + std::to_string(i) + ": texel range outside the blob");
+    }
+  }
+  // nesting depth of checkers <= 7 (device loop bound)
+  std::vector<int> depth(d->n_textures, 0);
+  for (uint64_t i = 0; i < d->n_textures; i++)
+    if (d->textures[i].kind == RT_TEX_CHECKER) {
+      depth[i] = 1 + std::max(depth[(size_t)d->textures[i].odd], depth[(size_t)d->textures[i].even]);
+      if (depth[i] > 7) return fail(ctx, RT_E_UNSUPPORTED, "checker textures nested deeper than 7");
+    }
+  return RT_OK;
+}
+
+int rt_scene_free(rt_ctx* ctx, rt_scene* s) {
+  if (!s) return RT_OK;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (s->d_nodes) (void)hipFree(s->d_nodes);
+  if (s->d_prims) (void)hipFree(s->d_prims);
+  if (s->d_mats) (void)hipFree(s->d_mats);
+  if (s->d_texs) (void)hipFree(s->d_texs);
+  if (s->d_texels) (void)hipFree(s->d_texels);
+  delete s;
+  return RT_OK;
+}
+
+static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) {
+  if (d->n_prims == 0) return fail(ctx, RT_E_INVALID_ARG, "scene has no primitives");
+  if (d->n_prims > (1u << 30)) return fail(ctx, RT_E_UNSUPPORTED, "too many primitives");
+  if (!d->prims || !d->materials || d->n_materials == 0) return fail(ctx, RT_E_INVALID_ARG, "prims/materials missing");
+  if (d->n_textures && !d->textures) return fail(ctx, RT_E_INVALID_ARG, "textures missing");
+  int rc = validate_texture_graph(ctx, d);
+  if (rc) return rc;
+  for (uint64_t i = 0; i < d->n_materials; i++) {
+    const rt_material& m = d->materials[i];
+    if (m.kind > RT_MAT_ISOTROPIC) return fail(ctx, RT_E_INVALID_ARG, "material " + std::to_string(i) + ": unknown kind");
+    bool needs_tex = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+    if (needs_tex && (m.tex < 0 || (uint64_t)m.tex >= d->n_textures))
+      return fail(ctx, RT_E_INVALID_ARG, "material " + std::to_string(i) + ": texture index out of range");
+  }
+  std::vector<Prim> prims(d->n_prims);
+  std::vector<rtb::Box> boxes(d->n_prims);
+  for (uint64_t i = 0; i < d->n_prims; i++) {
+    const rt_prim& p = d->prims[i];
+    Prim& q = prims[i];
+    memset(&q, 0, sizeof(q));
+    if (p.material_id >= d->n_materials)
+      return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": material_id out of range");
+    q.type = p.type;
+    q.mat = p.material_id;
+    q.obj = p.object_id;
+    rtb::Box& b = boxes[i];
+    if (p.type == RT_PRIM_SPHERE || p.type == RT_PRIM_MOVING_SPHERE) {
+      const double* c1 = p.type == RT_PRIM_MOVING_SPHERE ? p.b : p.a;
+      if (!finite3(p.a) || !finite3(c1) || !std::isfinite(p.radius) || p.radius == 0.0)
+        return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": non-finite sphere or zero radius");
+      for (int a = 0; a < 3; a++) {
+        q.f[a] = p.a[a];
+        q.f[3 + a] = c1[a];
+        // geometry.rs:20-28,90-100: box of center -/+ radius (ordered: radius may be negative), union over
+        // both end points for a moving sphere
+        double r = std::fabs(p.radius);
+        b.lo[a] = std::fmin(p.a[a], c1[a]) - r;
+        b.hi[a] = std::fmax(p.a[a], c1[a]) + r;
+      }
+      q.f[6] = p.radius;
+    } else if (p.type == RT_PRIM_QUAD) {
+      if (!finite3(p.a) || !finite3(p.b) || !finite3(p.c))
+        return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": non-finite quad");
+      const double *Q = p.a, *u = p.b, *v = p.c;
+      double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+      double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (!(len > 0)) return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": degenerate quad");
+      for (int a = 0; a < 3; a++) {
+        q.f[a] = Q[a]; q.f[3 + a] = u[a]; q.f[6 + a] = v[a]; q.f[9 + a] = n[a] / len;
+        double c[4] = {Q[a], Q[a] + u[a], Q[a] + v[a], Q[a] + u[a] + v[a]};
+        b.lo[a] = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3]));
+        b.hi[a] = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3]));
+        if (b.hi[a] - b.lo[a] < 0.0001) { b.lo[a] -= 0.00005; b.hi[a] += 0.00005; }
+      }
+      q.f[12] = q.f[9] * Q[0] + q.f[10] * Q[1] + q.f[11] * Q[2];
+      q.f[13] = 1.0 / len;
+    } else {
+      return fail(ctx, RT_E_UNSUPPORTED, "prim " + std::to_string(i) + ": primitive type not supported yet");
+    }
+  }
+  rtb::BuildResult bvh = rtb::build_bvh(boxes, RT_STACK_DEPTH);
+  sc->bvh_depth = bvh.depth;
+  if (bvh.depth >= RT_STACK_DEPTH) return fail(ctx, RT_E_INTERNAL, "BVH deeper than the traversal stack");
+
+  std::vector<Material> mats(d->n_materials);
+  for (uint64_t i = 0; i < d->n_materials; i++) {
+    const rt_material& m = d->materials[i];
+    Material& o = mats[i];
+    memset(&o, 0, sizeof(o));
+    o.kind = m.kind;
+    o.tex = m.tex;
+    for (int a = 0; a < 3; a++) o.albedo[a] = (float)m.albedo[a];
+    o.fuzz = (float)m.fuzz;
+    o.ior = (float)m.ior;
+  }
+  std::vector<Texture> texs(std::max<uint64_t>(d->n_textures, 1));
+  memset(texs.data(), 0, texs.size() * sizeof(Texture));
+  for (uint64_t i = 0; i < d->n_textures; i++) {
+    const rt_texture& t = d->textures[i];
+    Texture& o = texs[i];
+    o.kind = t.kind;
+    o.odd = t.odd;
+    o.even = t.even;
+    o.width = t.width;
+    o.height = t.height;
+    o.texel_off = (uint32_t)(t.texel_offset / 4);
+    for (int a = 0; a < 3; a++) o.rgb[a] = (float)t.rgb[a];
+    o.inv_scale = t.inv_scale;
+  }
+  static_assert(sizeof(rtb::FlatNode) == sizeof(BvhNode), "node layout mismatch");
+  size_t n_nodes = std::max<size_t>(bvh.nodes.size(), 1);
+  HIP_TRY(ctx, hipMalloc(&sc->d_nodes, n_nodes * sizeof(BvhNode)));
+  if (!bvh.nodes.empty())
+    HIP_TRY(ctx, hipMemcpy(sc->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMalloc(&sc->d_prims, prims.size() * sizeof(Prim)));
+  HIP_TRY(ctx, hipMemcpy(sc->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMalloc(&sc->d_mats, mats.size() * sizeof(Material)));
+  HIP_TRY(ctx, hipMemcpy(sc->d_mats, mats.data(), mats.size() * sizeof(Material), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMalloc(&sc->d_texs, texs.size() * sizeof(Texture)));
+  HIP_TRY(ctx, hipMemcpy(sc->d_texs, texs.data(), texs.size() * sizeof(Texture), hipMemcpyHostToDevice));
+  if (d->n_texel_bytes) {
+    HIP_TRY(ctx, hipMalloc(&sc->d_texels, (d->n_texel_bytes + 3) & ~3ull));
+    HIP_TRY(ctx, hipMemcpy(sc->d_texels, d->texels, d->n_texel_bytes, hipMemcpyHostToDevice));
+  }
+  sc->view.nodes = sc->d_nodes;
+  sc->view.prims = sc->d_prims;
+  sc->view.mats = sc->d_mats;
+  sc->view.texs = sc->d_texs;
+  sc->view.texels = sc->d_texels;
+  sc->view.noise_table = ctx->d_noise_table;
+  sc->view.n_nodes = (int32_t)bvh.nodes.size();
+  sc->view.n_prims = (int32_t)prims.size();
+  sc->view.n_mats = (int32_t)mats.size();
+  sc->view.n_texs = (int32_t)d->n_textures;
+  sc->view.root = bvh.root;
+  return RT_OK;
+}
+
+int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!desc || !out) return fail(ctx, RT_E_INVALID_ARG, "rt_scene_upload: NULL argument");
+  *out = nullptr;
+  try {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rt_scene* sc = new rt_scene();
+    int rc = scene_upload_impl(ctx, desc, sc);
+    if (rc != RT_OK) {
+      rt_scene_free(ctx, sc);
+      return rc;
+    }
+    *out = sc;
+    return RT_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(ctx, RT_E_OOM, "rt_scene_upload: out of host memory");
+  } catch (...) {
+    return fail(ctx, RT_E_INTERNAL, "rt_scene_upload: unexpected exception");
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ probe
+int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_t n, rt_hit* out_hits) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!scene || (n && (!rays || !out_hits))) return fail(ctx, RT_E_INVALID_ARG, "rt_intersect: NULL argument");
+  if (n == 0) return RT_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t CH = 1u << 22;
+  uint64_t chunk = n < CH ? n : CH;
+  rt_ray* d_rays = nullptr;
+  rt_hit* d_hits = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_rays, chunk * sizeof(rt_ray)));
+  hipError_t e = hipMalloc(&d_hits, chunk * sizeof(rt_hit));
+  if (e != hipSuccess) {
+    (void)hipFree(d_rays);
+    return fail(ctx, RT_E_OOM, "rt_intersect: hipMalloc failed");
+  }
+  int rc = RT_OK;
+  for (uint64_t off = 0; off < n && rc == RT_OK; off += chunk) {
+    uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - off);
+    uint32_t blocks = std::min<uint32_t>((m + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)ctx->n_cu * 8);
+    if ((e = hipMemcpyAsync(d_rays, rays + off, (size_t)m * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
+    hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, d_rays, m, d_hits);
+    if ((e = hipGetLastError()) != hipSuccess) { rc = RT_E_HIP; break; }
+    if ((e = hipMemcpyAsync(out_hits + off, d_hits, (size_t)m * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
+  }
+  (void)hipFree(d_rays);
+  (void)hipFree(d_hits);
+  if (rc != RT_OK) ctx->err = std::string("rt_intersect: ") + hipGetErrorString(e);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ render
+static int ensure_work(rt_ctx* ctx, size_t cap, uint32_t depth) {
+  if (ctx->wb.cap < cap) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_work(ctx);
+    // per path: 2 queues x (7 f64 + 3 f32 + 1 u32) + hits (i32 + f64) + L (3 f32)
+    const size_t capa = (cap + 63) & ~(size_t)63;
+    const size_t per_q = capa * (7 * 8 + 3 * 4 + 4);
+    const size_t total = 2 * per_q + capa * (4 + 8) + capa * 12;
+    HIP_TRY(ctx, hipMalloc(&ctx->wb.slab, total));
+    char* p = (char*)ctx->wb.slab;
+    auto take = [&](size_t bytes) { char* r = p; p += bytes; return r; };
+    ctx->wb.hits.t = (double*)take(capa * 8);
+    for (int k = 0; k < 2; k++) {
+      Queue& q = ctx->wb.q[k];
+      q.ox = (double*)take(capa * 8); q.oy = (double*)take(capa * 8); q.oz = (double*)take(capa * 8);
+      q.dx = (double*)take(capa * 8); q.dy = (double*)take(capa * 8); q.dz = (double*)take(capa * 8);
+      q.time = (double*)take(capa * 8);
+    }
+    for (int k = 0; k < 2; k++) {
+      Queue& q = ctx->wb.q[k];
+      q.tr = (float*)take(capa * 4); q.tg = (float*)take(capa * 4); q.tb = (float*)take(capa * 4);
+      q.id = (uint32_t*)take(capa * 4);
+    }
+    ctx->wb.hits.prim = (int32_t*)take(capa * 4);
+    ctx->wb.Lr = (float*)take(capa * 4); ctx->wb.Lg = (float*)take(capa * 4); ctx->wb.Lb = (float*)take(capa * 4);
+    ctx->wb.cap = capa;
+  }
+  if (ctx->counts_cap < (size_t)depth + 2) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    ctx->d_counts = nullptr;
+    ctx->counts_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_counts, ((size_t)depth + 2) * 4));
+    ctx->counts_cap = (size_t)depth + 2;
+  }
+  return RT_OK;
+}
+
+static int to_device_camera(rt_ctx* ctx, const rt_camera* c, Camera& o) {
+  if (c->width == 0 || c->height == 0) return fail(ctx, RT_E_INVALID_ARG, "camera: zero image size");
+  if ((uint64_t)c->width * c->height > 0x3FFFFFFFull) return fail(ctx, RT_E_UNSUPPORTED, "camera: image too large");
+  if (c->sampler_kind > RT_SAMPLER_RANDOM) return fail(ctx, RT_E_INVALID_ARG, "camera: unknown sampler kind");
+  if (c->sampler_n == 0) return fail(ctx, RT_E_INVALID_ARG, "camera: sampler_n must be >= 1");
+  if (c->sampler_kind == RT_SAMPLER_UNIFORM && c->sampler_n > 65535) return fail(ctx, RT_E_INVALID_ARG, "camera: grid side too large");
+  if (c->background_mode > 1) return fail(ctx, RT_E_INVALID_ARG, "camera: unknown background mode");
+  for (int a = 0; a < 3; a++) {
+    o.center[a] = c->center[a]; o.pixel00[a] = c->pixel00[a]; o.du[a] = c->du[a]; o.dv[a] = c->dv[a];
+    o.dfu[a] = c->defocus_u[a]; o.dfv[a] = c->defocus_v[a];
+    o.background[a] = (float)c->background[a];
+  }
+  if (!finite3(c->center) || !finite3(c->pixel00) || !finite3(c->du) || !finite3(c->dv))
+    return fail(ctx, RT_E_INVALID_ARG, "camera: non-finite frame vectors");
+  o.defocus_angle = c->defocus_angle;
+  o.width = c->width; o.height = c->height; o.sampler_kind = c->sampler_kind; o.sampler_n = c->sampler_n;
+  o.max_depth = c->max_depth; o.background_mode = c->background_mode;
+  return RT_OK;
+}
+
+struct StageTimer {
+  rt_ctx* ctx;
+  hipStream_t st;
+  explicit StageTimer(rt_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+  void begin() { if (ctx->profile) (void)hipEventRecord(ctx->ev_a, st); }
+  void end(float& acc) {
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->ev_b, st);
+    (void)hipEventSynchronize(ctx->ev_b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b);
+    acc += ms;
+  }
+};
+
+int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+                     uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!scene || !cam || !d_out_sum) return fail(ctx, RT_E_INVALID_ARG, "rt_render: NULL argument");
+  if (sample_stride == 0) return fail(ctx, RT_E_INVALID_ARG, "rt_render: sample_stride must be >= 1");
+  Camera dc;
+  int rc = to_device_camera(ctx, cam, dc);
+  if (rc) return rc;
+  const uint64_t spp_total = cam->sampler_kind == RT_SAMPLER_UNIFORM ? (uint64_t)cam->sampler_n * cam->sampler_n : cam->sampler_n;
+  if (sample_end > spp_total) return fail(ctx, RT_E_INVALID_ARG, "rt_render: sample_end exceeds the sampler's sample count");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  const uint32_t n_pix = cam->width * cam->height;
+  const uint32_t K = sample_begin < sample_end ? (sample_end - sample_begin + sample_stride - 1) / sample_stride : 0;
+  ctx->stats = rt_stats();
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+  HIP_TRY(ctx, hipMemsetAsync(d_out_sum, 0, (size_t)n_pix * 3 * sizeof(float), st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ray_total, 0, sizeof(unsigned long long), st));
+  if (K > 0 && cam->max_depth > 0) {
+    // pass plan: all pixels x S samples when that fits max_paths, else pixel chunks x 1 sample
+    const uint64_t cap = (uint64_t)ctx->max_paths;
+    uint32_t pix_chunk = n_pix, S = K;
+    if ((uint64_t)n_pix * K > cap) {
+      if (n_pix <= cap) S = (uint32_t)std::max<uint64_t>(1, cap / n_pix);
+      else { S = 1; pix_chunk = (uint32_t)cap; }
+    }
+    rc = ensure_work(ctx, (size_t)pix_chunk * S, cam->max_depth);
+    if (rc) return rc;
+    const uint32_t depth = cam->max_depth;
+    const uint32_t max_blocks = (uint32_t)ctx->n_cu * 8;
+    StageTimer tm(ctx, st);
+    for (uint32_t pix0 = 0; pix0 < n_pix; pix0 += pix_chunk) {
+      const uint32_t npp = std::min(pix_chunk, n_pix - pix0);
+      for (uint32_t kk = 0; kk < K; kk += S) {
+        const uint32_t Sp = std::min(S, K - kk);
+        PassParams pp;
+        pp.n_paths = npp * Sp; pp.pix0 = pix0; pp.S = Sp;
+        pp.s_first = sample_begin + kk * sample_stride; pp.s_stride = sample_stride;
+        pp.k0 = (uint32_t)seed; pp.k1 = (uint32_t)(seed >> 32);
+        const uint32_t blocks = std::min<uint32_t>((pp.n_paths + RT_BLOCK - 1) / RT_BLOCK, max_blocks);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)depth + 2) * 4, st));
+        tm.begin();
+        hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(RT_BLOCK), 0, st, dc, ctx->wb.q[0], ctx->wb.Lr, ctx->wb.Lg,
+                           ctx->wb.Lb, pp, ctx->d_counts);
+        tm.end(ctx->stats.ms_generate);
+        for (uint32_t b = 0; b < depth; b++) {
+          Queue& qi = ctx->wb.q[b & 1];
+          Queue& qo = ctx->wb.q[(b + 1) & 1];
+          tm.begin();
+          hipLaunchKernelGGL(k_intersect, dim3(blocks), dim3(RT_BLOCK), 0, st, scene->view, qi, ctx->wb.hits,
+                             ctx->d_counts + b);
+          tm.end(ctx->stats.ms_intersect);
+          tm.begin();
+          hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(RT_BLOCK), 0, st, scene->view, dc, qi, ctx->wb.hits, qo,
+                             ctx->d_counts + b, ctx->d_counts + b + 1, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb, pp, b,
+                             (uint32_t)(b + 1 == depth));
+          tm.end(ctx->stats.ms_shade);
+          ctx->stats.bounces_run++;
+          ctx->stats.intersect_launches++;
+        }
+        tm.begin();
+        const uint32_t ablocks = std::min<uint32_t>((npp + RT_BLOCK - 1) / RT_BLOCK, max_blocks);
+        hipLaunchKernelGGL(k_accumulate, dim3(ablocks), dim3(RT_BLOCK), 0, st, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb,
+                           d_out_sum, pp, npp, ctx->d_counts, depth, ctx->d_ray_total);
+        tm.end(ctx->stats.ms_accumulate);
+        ctx->stats.passes++;
+        ctx->stats.paths += pp.n_paths;
+      }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
+  ctx->timing_pending = true;
+  return RT_OK;
+}
+
+int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+              uint32_t sample_end, uint32_t sample_stride, float* out_sum) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!scene || !cam || !out_sum) return fail(ctx, RT_E_INVALID_ARG, "rt_render: NULL argument");
+  if (cam->width == 0 || cam->height == 0) return fail(ctx, RT_E_INVALID_ARG, "camera: zero image size");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)cam->width * cam->height * 3 * sizeof(float);
+  float* d_out = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_out, bytes));
+  int rc = rt_render_device(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out, nullptr);
+  if (rc == RT_OK) {
+    hipError_t e = hipMemcpyAsync(out_sum, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, RT_E_HIP, std::string("rt_render: ") + hipGetErrorString(e));
+  }
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
+  if (!ctx || !out) return RT_E_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->timing_pending) {
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    ctx->stats.ms_total = ms;
+    unsigned long long rays = 0;
+    HIP_TRY(ctx, hipMemcpy(&rays, ctx->d_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
+    ctx->stats.rays = rays;
+    ctx->timing_pending = false;
+  }
+  *out = ctx->stats;
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ resolve
+int rt_resolve_device(rt_ctx* ctx, const float* d_sum, uint32_t width, uint32_t height, uint32_t spp, double gamma,
+                      double* d_out_rgb, uint8_t* d_out_rgb8, void* hip_stream) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!d_sum || width == 0 || height == 0 || spp == 0 || !(gamma > 0))
+    return fail(ctx, RT_E_INVALID_ARG, "rt_resolve: bad argument");
+  if ((uint64_t)width * height > 0x3FFFFFFFull) return fail(ctx, RT_E_UNSUPPORTED, "rt_resolve: image too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  const uint32_t n = width * height * 3;
+  const uint32_t blocks = std::min<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)ctx->n_cu * 8);
+  hipLaunchKernelGGL(k_resolve, dim3(blocks), dim3(RT_BLOCK), 0, st, d_sum, n, 1.0 / (double)spp, 1.0 / gamma,
+                     d_out_rgb, d_out_rgb8);
+  HIP_TRY(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_resolve(rt_ctx* ctx, const float* sum, uint32_t width, uint32_t height, uint32_t spp, double gamma,
+               double* out_rgb, uint8_t* out_rgb8) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!sum || width == 0 || height == 0) return fail(ctx, RT_E_INVALID_ARG, "rt_resolve: bad argument");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)width * height * 3;
+  float* d_sum = nullptr;
+  double* d_rgb = nullptr;
+  uint8_t* d_u8 = nullptr;
+  int rc = RT_OK;
+  hipError_t e = hipMalloc(&d_sum, n * 4);
+  if (e == hipSuccess && out_rgb) e = hipMalloc(&d_rgb, n * 8);
+  if (e == hipSuccess && out_rgb8) e = hipMalloc(&d_u8, n);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_sum, sum, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    rc = rt_resolve_device(ctx, d_sum, width, height, spp, gamma, d_rgb, d_u8, nullptr);
+    if (rc == RT_OK && out_rgb) e = hipMemcpyAsync(out_rgb, d_rgb, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == RT_OK && e == hipSuccess && out_rgb8) e = hipMemcpyAsync(out_rgb8, d_u8, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (d_sum) (void)hipFree(d_sum);
+  if (d_rgb) (void)hipFree(d_rgb);
+  if (d_u8) (void)hipFree(d_u8);
+  if (rc == RT_OK && e != hipSuccess) rc = fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, std::string("rt_resolve: ") + hipGetErrorString(e));
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,435 @@
+// raytracer.cpp — host-side mirror of the reference API over the C ABI (see raytracer.hpp).
+#include "raytracer.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace raytracer {
+
+// ------------------------------------------------------------------ random.rs
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+uint64_t Rng::next_u64() {  // random.rs:18-28
+  const uint64_t a = s_[0], b = s_[1];
+  const uint64_t sum = a + b;
+  const uint64_t c = a ^ b;
+  s_[0] = rotl64(a, 24) ^ c ^ (c << 16);
+  s_[1] = rotl64(c, 37);
+  return sum;
+}
+Rng& Rng::jump_impl(const uint64_t jumper[2]) {  // random.rs:37-53
+  uint64_t acc0 = 0, acc1 = 0;
+  for (int word = 0; word < 2; ++word)
+    for (int bit = 0; bit < 64; ++bit) {
+      if ((jumper[word] >> bit) & 1ULL) { acc0 ^= s_[0]; acc1 ^= s_[1]; }
+      next_u64();
+    }
+  s_[0] = acc0;
+  s_[1] = acc1;
+  return *this;
+}
+Rng& Rng::short_jump() {  // random.rs:54-57
+  static const uint64_t k[2] = {0xdf900294d8f554a5ULL, 0x170865df4b3201fcULL};
+  return jump_impl(k);
+}
+Rng& Rng::long_jump() {  // random.rs:58-61
+  static const uint64_t k[2] = {0xd2a98b26625eee7bULL, 0xdddf9b1090aa7ac1ULL};
+  return jump_impl(k);
+}
+
+static uint8_t sat_u8(double v) {  // Rust `as u8`
+  if (!(v == v) || v <= 0.0) return 0;
+  if (v >= 255.0) return 255;
+  return (uint8_t)v;
+}
+std::tuple<uint8_t, uint8_t, uint8_t> Color::into_u8() const {
+  return {sat_u8(256.0 * r), sat_u8(256.0 * g), sat_u8(256.0 * b)};
+}
+
+// ------------------------------------------------------------------ describe(): flatten the trait objects
+rt_scene_desc FlatScene::desc() const {
+  rt_scene_desc d;
+  std::memset(&d, 0, sizeof(d));
+  d.prims = prims.data();
+  d.n_prims = prims.size();
+  d.materials = materials.data();
+  d.n_materials = materials.size();
+  d.textures = textures.data();
+  d.n_textures = textures.size();
+  d.texels = texels.empty() ? nullptr : texels.data();
+  d.n_texel_bytes = texels.size();
+  return d;
+}
+static rt_texture blank_texture(uint32_t kind) {
+  rt_texture t;
+  std::memset(&t, 0, sizeof(t));
+  t.kind = kind;
+  t.odd = t.even = -1;
+  return t;
+}
+template <class F>
+static int32_t intern(std::map<const void*, int32_t>& ids, const void* key, F&& make) {
+  auto it = ids.find(key);
+  if (it != ids.end()) return it->second;
+  int32_t id = make();
+  ids[key] = id;
+  return id;
+}
+int32_t SolidColor::describe(FlatScene& out) const {
+  return intern(out.texture_ids, this, [&] {
+    rt_texture t = blank_texture(RT_TEX_SOLID);
+    t.rgb[0] = color_.r; t.rgb[1] = color_.g; t.rgb[2] = color_.b;
+    out.textures.push_back(t);
+    return (int32_t)out.textures.size() - 1;
+  });
+}
+int32_t CheckerTexture::describe(FlatScene& out) const {
+  return intern(out.texture_ids, this, [&] {
+    // children first: the ABI requires checker children to precede the checker (acyclic by construction)
+    int32_t o = odd_->describe(out), e = even_->describe(out);
+    rt_texture t = blank_texture(RT_TEX_CHECKER);
+    t.inv_scale = inv_scale_;
+    t.odd = o;
+    t.even = e;
+    out.textures.push_back(t);
+    return (int32_t)out.textures.size() - 1;
+  });
+}
+int32_t ImageTexture::describe(FlatScene& out) const {
+  return intern(out.texture_ids, this, [&] {
+    rt_texture t = blank_texture(RT_TEX_IMAGE);
+    t.width = image_.width;
+    t.height = image_.height;
+    t.texel_offset = out.texels.size();
+    out.texels.insert(out.texels.end(), image_.data.begin(), image_.data.end());
+    out.textures.push_back(t);
+    return (int32_t)out.textures.size() - 1;
+  });
+}
+int32_t NoiseTexture::describe(FlatScene& out) const {
+  return intern(out.texture_ids, this, [&] {
+    rt_texture t = blank_texture(RT_TEX_NOISE);
+    t.inv_scale = inv_scale_;
+    out.textures.push_back(t);
+    return (int32_t)out.textures.size() - 1;
+  });
+}
+static rt_material blank_material(uint32_t kind) {
+  rt_material m;
+  std::memset(&m, 0, sizeof(m));
+  m.kind = kind;
+  m.tex = -1;
+  return m;
+}
+int32_t Lambertian::describe(FlatScene& out) const {
+  return intern(out.material_ids, this, [&] {
+    rt_material m = blank_material(RT_MAT_LAMBERTIAN);
+    m.tex = albedo->describe(out);
+    out.materials.push_back(m);
+    return (int32_t)out.materials.size() - 1;
+  });
+}
+int32_t Metal::describe(FlatScene& out) const {
+  return intern(out.material_ids, this, [&] {
+    rt_material m = blank_material(RT_MAT_METAL);
+    m.albedo[0] = albedo_.r; m.albedo[1] = albedo_.g; m.albedo[2] = albedo_.b;
+    m.fuzz = fuzz_;
+    out.materials.push_back(m);
+    return (int32_t)out.materials.size() - 1;
+  });
+}
+int32_t Dielectric::describe(FlatScene& out) const {
+  return intern(out.material_ids, this, [&] {
+    rt_material m = blank_material(RT_MAT_DIELECTRIC);
+    m.ior = ior_;
+    out.materials.push_back(m);
+    return (int32_t)out.materials.size() - 1;
+  });
+}
+static rt_prim blank_prim(uint32_t type, int32_t object_id, int32_t material) {
+  rt_prim p;
+  std::memset(&p, 0, sizeof(p));
+  p.type = type;
+  p.object_id = object_id;
+  p.material_id = (uint32_t)material;
+  return p;
+}
+void Sphere::describe(FlatScene& out) const {
+  rt_prim p = blank_prim(RT_PRIM_SPHERE, (int32_t)out.prims.size(), material->describe(out));
+  p.a[0] = center.x; p.a[1] = center.y; p.a[2] = center.z;
+  p.radius = radius;
+  out.prims.push_back(p);
+}
+void MovingSphere::describe(FlatScene& out) const {
+  rt_prim p = blank_prim(RT_PRIM_MOVING_SPHERE, (int32_t)out.prims.size(), sphere.material->describe(out));
+  p.a[0] = sphere.center.x; p.a[1] = sphere.center.y; p.a[2] = sphere.center.z;
+  p.b[0] = destination.x; p.b[1] = destination.y; p.b[2] = destination.z;
+  p.radius = sphere.radius;
+  out.prims.push_back(p);
+}
+void HittableList::describe(FlatScene& out) const {
+  for (const auto& o : objects) o->describe(out);
+}
+std::unique_ptr<Hittable> HittableList::into_bvh() { return std::make_unique<BVHNode>(std::move(objects)); }
+void BVHNode::describe(FlatScene& out) const {
+  for (const auto& o : objects_) o->describe(out);
+}
+
+// ------------------------------------------------------------------ camera
+ImageSpec ImageSpecBuilder::build() const {
+  if (!width_) throw Error("The image width must be set");
+  ImageSpec s;
+  s.width = *width_;
+  s.aspect_ratio = aspect_.value_or(1.0);
+  size_t h = (size_t)((double)s.width / s.aspect_ratio);
+  s.height = h < 1 ? 1 : h;
+  return s;
+}
+
+Camera CameraBuilder::build() const {  // builder.rs:55-134
+  if (!image_spec_) throw Error("The image specifications must be set");
+  if (!sampler_) throw Error("The samples per pixel must be set");
+  Camera c;
+  if (sampler_->kind == PixelSamplerKind::Uniform) {
+    const double root = std::sqrt((double)sampler_->n);
+    if (root != std::floor(root))
+      throw Error("samples_per_pixel in the grid sampler must be a square number, current value: " +
+                  std::to_string(sampler_->n));
+    c.pixel_sampler = PixelSampler{PixelSamplerKind::Uniform, (size_t)root};
+  } else {
+    c.pixel_sampler = *sampler_;
+  }
+  if (!max_ray_depth_) throw Error("The depth must be set");
+  c.depth = *max_ray_depth_;
+  c.field_of_view = field_of_view_.value_or(90.0);
+  c.lookfrom = lookfrom_.value_or(Point3(0., 0., 0.));
+  c.lookat = lookat_.value_or(Point3(0., 0., -1.));
+  c.up_vector = up_vector_.value_or(Vec3(0., 1., 0.));
+  c.defocus_angle = defocus_angle_.value_or(0.0);
+  c.focus_distance = focus_distance_.value_or(c.lookfrom.distance(c.lookat));
+  c.aspect_ratio = image_spec_->aspect_ratio;
+  c.image_width = image_spec_->width;
+  c.image_height = image_spec_->height;
+
+  const double pi = 3.14159265358979323846264338327950288;
+  c.center = c.lookfrom;
+  const double h = std::tan(c.field_of_view * (pi / 180.0) / 2.0);
+  const double viewport_height = 2.0 * h * c.focus_distance;
+  const double viewport_width = viewport_height * (double)c.image_width / (double)c.image_height;
+  c.w = (c.lookfrom - c.lookat).unit_vector();
+  c.u = c.up_vector.cross(c.w).unit_vector();
+  c.v = c.w.cross(c.u);
+  const Vec3 viewport_u = viewport_width * c.u;
+  const Vec3 viewport_v = viewport_height * (-c.v);
+  c.pixel_delta_u = viewport_u / (double)c.image_width;
+  c.pixel_delta_v = viewport_v / (double)c.image_height;
+  const Vec3 upper_left = c.center - (c.focus_distance * c.w) - viewport_u / 2. - viewport_v / 2.;
+  c.pixel00_loc = upper_left + 0.5 * (c.pixel_delta_u + c.pixel_delta_v);
+  const double defocus_radius = c.focus_distance * std::tan((c.defocus_angle / 2.0) * (pi / 180.0));
+  c.defocus_disk_u = defocus_radius * c.u;
+  c.defocus_disk_v = defocus_radius * c.v;
+  return c;
+}
+
+size_t Camera::samples_per_pixel() const {
+  return pixel_sampler.kind == PixelSamplerKind::Uniform ? pixel_sampler.n * pixel_sampler.n : pixel_sampler.n;
+}
+
+rt_camera Camera::abi_camera() const {
+  rt_camera c;
+  std::memset(&c, 0, sizeof(c));
+  c.width = (uint32_t)image_width;
+  c.height = (uint32_t)image_height;
+  c.sampler_kind = pixel_sampler.kind == PixelSamplerKind::Uniform ? RT_SAMPLER_UNIFORM : RT_SAMPLER_RANDOM;
+  c.sampler_n = (uint32_t)pixel_sampler.n;
+  c.max_depth = (uint32_t)depth;
+  c.background_mode = 0;
+  auto put = [](double* dst, const Vec3& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+  put(c.center, center);
+  put(c.pixel00, pixel00_loc);
+  put(c.du, pixel_delta_u);
+  put(c.dv, pixel_delta_v);
+  put(c.defocus_u, defocus_disk_u);
+  put(c.defocus_v, defocus_disk_v);
+  c.defocus_angle = defocus_angle;
+  return c;
+}
+
+namespace {
+struct SceneGuard {  // frees the device scene on every exit path
+  rt_ctx* ctx;
+  rt_scene* sc = nullptr;
+  ~SceneGuard() { if (sc) rt_scene_free(ctx, sc); }
+};
+void check(rt_ctx* ctx, int rc, const char* what) {
+  if (rc != RT_OK) throw Error(std::string(what) + " failed (" + std::to_string(rc) + "): " + rt_last_error(ctx));
+}
+}  // namespace
+
+std::vector<float> Camera::render_partial_sums(const Hittable& world, const RenderTarget& target) const {
+  if (!target.ctx) throw Error("RenderTarget.ctx is null: the GPU backend is required (no CPU fallback)");
+  if (target.world_size == 0 || target.rank >= target.world_size) throw Error("RenderTarget: bad rank/world_size");
+  FlatScene flat;
+  world.describe(flat);
+  rt_scene_desc desc = flat.desc();
+  SceneGuard g{target.ctx};
+  check(target.ctx, rt_scene_upload(target.ctx, &desc, &g.sc), "rt_scene_upload");
+  rt_camera cam = abi_camera();
+  std::vector<float> sums(image_width * image_height * 3);
+  check(target.ctx,
+        rt_render(target.ctx, g.sc, &cam, target.seed, target.rank, (uint32_t)samples_per_pixel(), target.world_size,
+                  sums.data()),
+        "rt_render");
+  return sums;
+}
+
+void Camera::render(const Hittable& world, const TileSender& sender, const RenderTarget& target) const {
+  if (target.world_size != 1)
+    throw Error("Camera::render renders whole frames; use render_partial_sums + a reduce for multi-GPU");
+  std::vector<float> sums = render_partial_sums(world, target);
+  const size_t pixel_count = image_width * image_height;
+  std::vector<double> rgb(pixel_count * 3);
+  check(target.ctx,
+        rt_resolve(target.ctx, sums.data(), (uint32_t)image_width, (uint32_t)image_height,
+                   (uint32_t)samples_per_pixel(), 2.2, rgb.data(), nullptr),
+        "rt_resolve");
+  std::vector<Color> image_buffer(pixel_count);
+  for (size_t i = 0; i < pixel_count; i++) image_buffer[i] = Color(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+  // mod.rs:64-78,102-114: the same 32x32 tile tuples, in tile-index order
+  const size_t rect = 32;
+  const size_t by = (image_height + rect - 1) / rect, bx = (image_width + rect - 1) / rect;
+  for (size_t index = 0; index < by * bx; index++) {
+    const size_t top = (index / bx) * rect, left = (index % bx) * rect;
+    const size_t h = std::min(rect, image_height - top), w = std::min(rect, image_width - left);
+    std::vector<Color> result(h * w);
+    for (size_t dy = 0; dy < h; dy++)
+      for (size_t dx = 0; dx < w; dx++) result[dy * w + dx] = image_buffer[(top + dy) * image_width + (left + dx)];
+    if (sender && !sender(Tile{{top, left}, {h, w}, std::move(result)})) {
+      std::printf("cancelled\n");  // mod.rs:110-113
+      return;
+    }
+  }
+  if (!target.ppm_path.empty()) write_buffer_to_file(target.ppm_path, image_buffer, image_width, image_height);
+}
+
+void Camera::write_buffer_to_file(const std::string& path, const std::vector<Color>& image_buffer, size_t width,
+                                  size_t height) {  // mod.rs:216-227, color.rs:74-81
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) throw Error("cannot create " + path);
+  std::fprintf(f, "P3\n%zu %zu\n255\n", width, height);
+  for (const Color& c : image_buffer) {
+    auto [r, g, b] = c.into_u8();
+    std::fprintf(f, "%u %u %u\n", r, g, b);
+  }
+  if (std::fclose(f) != 0) throw Error("write failed: " + path);
+}
+
+// ------------------------------------------------------------------ scene.rs
+Scene composition(CameraBuilder camera_builder) {  // scene.rs:35-87
+  Scene sc;
+  sc.camera = camera_builder.field_of_view(55.0)
+                  .lookfrom(Point3(0.0, 0.5, 1.0) * 1.5)
+                  .lookat(Point3(0.0, 0.3, 0.0))
+                  .up_vector(Vec3(0.0, 1.0, 0.0))
+                  .defocus_angle(0.0)
+                  .build();
+  auto world = std::make_unique<HittableList>();
+  // Ground
+  world->add(std::make_unique<Sphere>(Point3(0., -40000000.5, 0.), 40000000.,
+                                      std::make_shared<Lambertian>(Color(0.05, 0.20, 0.07))));
+  auto blue_lamb = std::make_shared<Lambertian>(Color(0.1, 0.1, 0.8));
+  auto red_lamb = std::make_shared<Lambertian>(Color(0.8, 0.1, 0.1));
+  world->add(std::make_unique<Sphere>(Point3(0., 0., -1.), 0.5, red_lamb));
+  world->add(std::make_unique<Sphere>(Point3(1.3, 0., -1.7), 0.5, blue_lamb));
+  world->add(std::make_unique<Sphere>(Point3(-0.25 - 0.125, -0.25, -0.5), 0.25, std::make_shared<Dielectric>(1.5)));
+  world->add(std::make_unique<Sphere>(Point3(-0.25 - 0.125, -0.25, -0.5), -0.20, std::make_shared<Dielectric>(1.5)));
+  world->add(std::make_unique<Sphere>(Point3(0.6, 0.1, -0.4), 0.3, std::make_shared<Dielectric>(1.5)));
+  world->add(std::make_unique<Sphere>(Point3(-1.0, 0., -1.0), 0.5, std::make_shared<Metal>(Color::gray(0.7), 0.0)));
+  sc.world = std::move(world);  // plain list (scene.rs:86)
+  return sc;
+}
+
+Scene book_cover(CameraBuilder camera_builder) {  // scene.rs:89-164
+  Scene sc;
+  sc.camera = camera_builder.field_of_view(20.0)
+                  .lookfrom(Point3(13.0, 2.0, 3.0))
+                  .lookat(Point3(0.0, 0.0, 0.0))
+                  .up_vector(Vec3(0.0, 1.0, 0.0))
+                  .defocus_angle(0.3)
+                  .focus_distance(10.0)
+                  .build();
+  Rng rng = Rng::from_seed(42, 1337);
+  auto world = std::make_unique<HittableList>();
+  std::shared_ptr<Texture> checker_texture =
+      std::make_shared<CheckerTexture>(0.32, std::make_shared<SolidColor>(Color(0.2, 0.3, 0.1)),
+                                       std::make_shared<SolidColor>(Color(0.9, 0.9, 0.9)));
+  world->add(std::make_unique<Sphere>(Point3(0.0, -1000.0, 0.0), 1000.0, std::make_shared<Lambertian>(checker_texture)));
+  for (int a = -11; a < 11; a++) {
+    for (int b = -11; b < 11; b++) {
+      const double choose_mat = rng.next_f64();
+      const double cx = (double)a + 0.9 * rng.next_f64();
+      const double cz = (double)b + 0.9 * rng.next_f64();
+      const Point3 center(cx, 0.2, cz);
+      if ((center - Point3(4.0, 0.2, 0.0)).length() > 0.9) {
+        std::shared_ptr<Material> sphere_material;
+        if (choose_mat < 0.7) {  // diffuse
+          const Color c1 = Color::random(rng);
+          const Color c2 = Color::random(rng);
+          sphere_material = std::make_shared<Lambertian>(c1 * c2);
+        } else if (choose_mat < 0.9) {  // metal
+          const Color albedo = Color::random(rng) / 2.0 + 0.5;
+          const double fuzz = rng.next_f64_range(0.0, 0.5);
+          sphere_material = std::make_shared<Metal>(albedo, fuzz);
+        } else {  // glass
+          sphere_material = std::make_shared<Dielectric>(1.5);
+        }
+        world->add(std::make_unique<MovingSphere>(Sphere(center, 0.2, sphere_material),
+                                                  center + Point3(0.0, 0.5 * (1. - choose_mat), 0.0)));
+      }
+    }
+  }
+  world->add(std::make_unique<Sphere>(Point3(0.0, 1.0, 0.0), 1.0, std::make_shared<Dielectric>(1.5)));
+  world->add(std::make_unique<Sphere>(Point3(-4.0, 1.0, 0.0), 1.0, std::make_shared<Lambertian>(Color::from_hex(0xffca3a))));
+  world->add(std::make_unique<Sphere>(Point3(4.0, 1.0, 0.0), 1.0, std::make_shared<Metal>(Color(0.8, 0.8, 0.8), 0.0)));
+  sc.world = world->into_bvh();
+  return sc;
+}
+
+Scene two_spheres(CameraBuilder camera_builder) {  // scene.rs:216-241
+  Scene sc;
+  sc.camera = camera_builder.field_of_view(20.0).lookfrom(Point3(13.0, 2.0, 3.0)).lookat(Point3(0.0, 0.0, 0.0)).build();
+  auto world = std::make_unique<HittableList>();
+  std::shared_ptr<Texture> checker_texture =
+      std::make_shared<CheckerTexture>(0.3, std::make_shared<SolidColor>(Color(0.2, 0.3, 0.1)),
+                                       std::make_shared<SolidColor>(Color(0.9, 0.9, 0.9)));
+  auto material = std::make_shared<Lambertian>(checker_texture);
+  world->add(std::make_unique<Sphere>(Point3(0.0, -10.0, 0.0), 10.0, material));
+  world->add(std::make_unique<Sphere>(Point3(0.0, 10.0, 0.0), 10.0, material));
+  sc.world = world->into_bvh();
+  return sc;
+}
+
+Scene earth(CameraBuilder camera_builder, RgbaImage earth_image) {  // scene.rs:243-260
+  Scene sc;
+  sc.camera = camera_builder.field_of_view(20.0).lookfrom(Point3(12.0, 0.0, 0.0)).lookat(Point3(0.0, 0.0, 0.0)).build();
+  auto world = std::make_unique<HittableList>();
+  std::shared_ptr<Texture> earth_texture = std::make_shared<ImageTexture>(std::move(earth_image));
+  auto material = std::make_shared<Lambertian>(earth_texture);
+  world->add(std::make_unique<Sphere>(Point3(0.0, 0.0, 0.0), 2.0, material));
+  sc.world = world->into_bvh();
+  return sc;
+}
+
+Scene something_blocky(CameraBuilder camera_builder) {  // scene.rs:262-285
+  Scene sc;
+  sc.camera = camera_builder.field_of_view(20.0).lookfrom(Point3(13.0, 2.0, 3.0)).lookat(Point3(0.0, 0.0, 0.0)).build();
+  auto world = std::make_unique<HittableList>();
+  std::shared_ptr<Texture> noise_texture = std::make_shared<NoiseTexture>(0.2);
+  auto material = std::make_shared<Lambertian>(noise_texture);
+  world->add(std::make_unique<Sphere>(Point3(0.0, -1000.0, 0.0), 1000.0, material));
+  world->add(std::make_unique<Sphere>(Point3(0.0, 2.0, 0.0), 2.0, material));
+  sc.world = world->into_bvh();
+  return sc;
+}
+
+}  // namespace raytracer
