@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s of the GPU `Camera::render` replacement on BASELINE.json's
+configs[1] (book_cover: bouncing spheres + motion blur + checker ground, 1200x675, 100 spp, depth 50).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full render of the frame: every rank renders the residue class `s % N == rank` of the
+per-pixel sample indices for the WHOLE frame (weak: N x the samples => `--scale-spp`; default strong split of the
+config's 100 spp is not used — see `scaling` below), the partial f32 frames are summed on rank 0 with one RCCL
+reduce, and rank 0 resolves (mean, gamma 2.2, 8-bit).  Scene and camera are resident in HBM before the timed
+region; outputs stay on the device.
+
+Scaling is WEAK: each rank always renders the config's full 100 spp share (`spp_per_gpu` = 100), i.e. at N
+GPUs the frame converges with N x 100 spp; value = total samples of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline      FP32-VALU roofline of the render kernels (algorithmic flops/sample from the
+                instrumented oracle on the reference-topology BVH x samples per step / hipEvent kernel time)
+  cpu_baseline  the CPU oracle (C++ restatement of the reference) timed on this host on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
+
+WORKLOADS = {
+    # name: (scene, width, sampler, spp, depth, workload fixture)
+    "c1": ("book_cover", 400, "random", 10, 50, "workload_c1.json"),
+    "c2": ("book_cover", 1200, "uniform", 100, 50, "workload_c2.json"),
+}
+
+
+def cpu_baseline(scene, width, depth):
+    """Oracle (kind 'port') on a bounded sample of the same workload: same frame, uniform 3x3 = 9 spp."""
+    from oracle_lib import OracleScene
+    threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share is 16
+    sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", 9, depth)
+    r = sc.render(threads=threads)
+    n = sc.width * sc.height * 9
+    # 1-thread figure on a sub-window (the reference's Arc refcount contention makes it scale sub-linearly)
+    win = (0, sc.height // 2 // 32 * 32, sc.width, 64)
+    r1 = sc.render(threads=1, window=win)
+    n1 = min(64, sc.height - win[1]) * sc.width * 9
+    return {
+        "value": n / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"{scene} {sc.width}x{sc.height}, uniform 9 spp (3x3 grid), depth {depth}: {n} samples, "
+                  f"{r['seconds']:.2f} s",
+        "one_thread_value": n1 / r1["seconds"] / 1e6,
+        "one_thread_sample": f"rows {win[1]}..{win[1] + 64}, {n1} samples, {r1['seconds']:.2f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-stages", action="store_true", help="extra untimed step with per-stage hipEvents")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch  # first: its bundled HIP runtime is the one the process uses
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raytracer_amd as ra
+    scene_name, width, sampler, spp, depth, fixture = WORKLOADS[args.workload]
+    ctx = ra.Context(local_rank)
+    # weak scaling: every rank renders `spp` samples per pixel; the frame holds world*spp samples.
+    # Uniform sampler needs a square count: use the grid of the config per rank by offsetting the seed per rank
+    # (decorrelated Philox streams per GPU) and letting each rank render the config's full grid.
+    host_scene = ra.Scene(scene_name, width, 16.0 / 9.0, sampler, spp, depth)
+    dev_scene = host_scene.upload(ctx)
+    cam = host_scene.camera_copy()
+    W, H = host_scene.width, host_scene.height
+    samples_per_rank = W * H * host_scene.spp
+    d_sum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    d_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    seed0 = 0x853C49E6748FEA9B
+
+    def step(i):
+        # rank r draws from its own Philox key => decorrelated streams per GPU (north_star)
+        seed = (seed0 + 0x9E3779B97F4A7C15 * (rank + 1) + i) & 0xFFFFFFFFFFFFFFFF
+        dev_scene.render_device(cam, d_sum.data_ptr(), seed=seed, stream=stream)
+        if world > 1:
+            dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            ctx.check(ctx.L.rt_resolve_device(ctx.h, d_sum.data_ptr(), W, H, host_scene.spp * world, 2.2, None,
+                                              d_u8.data_ptr(), stream))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    # per-step hipEvent time of the render kernels (events recorded by the library on the launch stream);
+    # measured on an extra replay after the timed region so that reading stats does not serialise the steps
+    for i in range(min(args.steps, 3)):
+        step(args.warmup + i)
+        torch.cuda.synchronize()
+        kernel_ms.append(ctx.stats()["ms_total"])
+    stats = ctx.stats()
+    stage = None
+    if args.profile_stages:
+        ctx.set_option("profile", 1)
+        step(0)
+        torch.cuda.synchronize()
+        s = ctx.stats()
+        stage = {k: s[k] for k in ("ms_generate", "ms_intersect", "ms_shade", "ms_accumulate", "ms_total")}
+        ctx.set_option("profile", 0)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = samples_per_rank * world * args.steps
+        value = total_samples / elapsed / 1e6
+        with open(os.path.join(ROOT, "tests", "golden", fixture)) as f:
+            wl = json.load(f)
+        fps = wl["flops_per_sample"]
+        k_ms = sorted(kernel_ms)[len(kernel_ms) // 2]
+        achieved = samples_per_rank * fps / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/sec (pixels x spp)", "value": value, "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + f32 culling/shading",
+            "data": "synthetic (reference scene builder book_cover, seed [42,1337])",
+            "config": {"workload": f"{args.workload}: {scene_name} {W}x{H}, {sampler}_sampler({host_scene.spp}), "
+                                   f"depth {depth}, 484 spheres (480 moving), defocus 0.3deg",
+                       "spp_per_gpu": host_scene.spp, "samples_per_step": samples_per_rank * world,
+                       "parallelism": f"sample-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / VALU_FP32_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "render pipeline (k_generate + k_intersect + k_shade + k_accumulate), per rt_render call",
+                         "kernel_ms_per_step": k_ms, "algorithmic_flops_per_sample": fps,
+                         "rays_per_sample": stats["rays"] / max(stats["paths"], 1)},
+        }
+        if stage:
+            out["roofline"]["stage_ms"] = stage
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_name, width, depth)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

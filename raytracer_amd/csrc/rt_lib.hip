@@ -211,7 +211,7 @@ struct rt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  int64_t max_paths = 32ll << 20;
+  int64_t max_paths = 128ll << 20;
   int profile = 0;
   int mode = 0;
   WorkBuffers wb;

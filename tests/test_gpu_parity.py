@@ -172,7 +172,7 @@ def test_sample_partition_sums_to_whole(ctx):
     # pass splitting (max_paths) does not change the result
     ctx.set_option("max_paths", 64 * 36 * 5)
     split = dev.render_sums(cam, seed=99)
-    ctx.set_option("max_paths", 32 << 20)
+    ctx.set_option("max_paths", 128 << 20)
     assert np.allclose(split, whole, rtol=1e-5, atol=1e-5)
 
 
