@@ -9,7 +9,7 @@
 #include <stdint.h>
 
 #define RT_BLOCK 256
-#define RT_STACK_DEPTH 32  // the host BVH builder guarantees tree depth <= RT_STACK_DEPTH
+#define RT_STACK_DEPTH 32  // the host BVH builder guarantees tree depth < RT_STACK_DEPTH
 #define RT_TMIN 0.000001   // src/camera/mod.rs:198
 
 namespace rtd {
@@ -33,6 +33,11 @@ struct __attribute__((aligned(128))) Prim {  // 128 B
   int32_t obj;
   uint32_t pad;
 };
+// compact 64-B sphere record (spheres-only scenes; this is what the fused kernel keeps in LDS)
+struct __attribute__((aligned(64))) SphereRec {
+  double c0[3], c1[3], r;
+  uint32_t type, mat;
+};
 
 struct Material {  // 32 B
   uint32_t kind;
@@ -54,12 +59,14 @@ struct Texture {  // 48 B
 struct Scene {
   const BvhNode* nodes;
   const Prim* prims;
+  const SphereRec* spheres;  // non-null iff every primitive is a (moving) sphere
   const Material* mats;
   const Texture* texs;
   const uint32_t* texels;    // RGBA8
-  const uint4* noise_table;  // 16 x 256 x 128-bit GF(2) table of the xoroshiro short jump (or null)
+  const uint4* noise_table;  // 16 x 256 x 128-bit GF(2) table of the xoroshiro short jump
   int32_t n_nodes, n_prims, n_mats, n_texs;
   int32_t root;  // >=0 node, <0 single leaf
+  int32_t bvh_depth;
 };
 
 struct Camera {
@@ -80,6 +87,13 @@ struct Hits {
   double* t;
 };
 
+// texture-kind / primitive-kind feature masks: kernels are specialised on what a scene actually contains
+#define RT_F_TEX_CHECKER 1u
+#define RT_F_TEX_IMAGE 2u
+#define RT_F_TEX_NOISE 4u
+#define RT_F_QUAD 8u
+#define RT_F_ALL 15u
+
 // ----------------------------------------------------------------------------------------------- RNG
 // Philox4x32-10 (Salmon et al., SC'11).  Counter = (pixel, sample, bounce, purpose), key = seed.
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -98,7 +112,7 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // purposes (counter word 3)
 #define RT_RNG_CAMERA 0x10000u   // subpixel x2, lens x2
 #define RT_RNG_CAMERA2 0x10001u  // time
-#define RT_RNG_SCATTER 0u        // + nothing: counter word 2 is the bounce
+#define RT_RNG_SCATTER 0u        // counter word 2 is the bounce
 
 __device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * 5.9604645e-8f + 2.9802322e-8f; }  // (0,1)
 __device__ __forceinline__ double u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
@@ -121,26 +135,76 @@ __device__ __forceinline__ f3 normalize(f3 a) {
   return inv * a;
 }
 
+// ----------------------------------------------------------------------------------------------- scene accessors
+// Where the traversal data lives.  GlobalAcc reads HBM/L2 through the vector cache; LdsAcc reads a
+// per-workgroup copy of the whole scene (nodes + 64-B sphere records) in LDS.
+struct PrimGeom {  // what the sphere path needs
+  d3 c0, c1;
+  double r;
+  uint32_t type, mat;
+};
+struct GlobalAcc {
+  const BvhNode* nodes;
+  const Prim* prims;
+  static constexpr bool kSpheresOnly = false;
+  __device__ __forceinline__ void node(int32_t i, float4& q0, float4& q1, float4& q2, int2& ch) const {
+    const float4* np = reinterpret_cast<const float4*>(nodes + i);
+    q0 = np[0]; q1 = np[1]; q2 = np[2];
+    ch = *reinterpret_cast<const int2*>(&np[3]);
+  }
+  __device__ __forceinline__ uint32_t type(int32_t pi) const { return prims[pi].type; }
+  __device__ __forceinline__ PrimGeom sphere(int32_t pi) const {
+    const Prim& P = prims[pi];
+    return {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, P.f[6], P.type, P.mat};
+  }
+  __device__ __forceinline__ const Prim& full(int32_t pi) const { return prims[pi]; }
+  __device__ __forceinline__ uint32_t mat(int32_t pi) const { return prims[pi].mat; }
+};
+template <class SphT>  // SphT = const SphereRec* in global or LDS address space (inferred after inlining)
+struct SphereAccT {
+  const float4* nodes;
+  SphT spheres;
+  const Prim* prims_unused;
+  static constexpr bool kSpheresOnly = true;
+  __device__ __forceinline__ void node(int32_t i, float4& q0, float4& q1, float4& q2, int2& ch) const {
+    const float4* np = nodes + 4 * i;
+    q0 = np[0]; q1 = np[1]; q2 = np[2];
+    float4 q3 = np[3];
+    ch = {__float_as_int(q3.x), __float_as_int(q3.y)};
+  }
+  __device__ __forceinline__ uint32_t type(int32_t pi) const { return spheres[pi].type; }
+  __device__ __forceinline__ PrimGeom sphere(int32_t pi) const {
+    const SphereRec& S = spheres[pi];
+    return {{S.c0[0], S.c0[1], S.c0[2]}, {S.c1[0], S.c1[1], S.c1[2]}, S.r, S.type, S.mat};
+  }
+  __device__ __forceinline__ const Prim& full(int32_t) const { return *prims_unused; }
+  __device__ __forceinline__ uint32_t mat(int32_t pi) const { return spheres[pi].mat; }
+};
+using SphereAcc = SphereAccT<const SphereRec*>;
+
 // ----------------------------------------------------------------------------------------------- intersection
 struct HitInfo {
   double t;
   int32_t prim;  // -1 = miss
 };
+struct TravCounters {
+  uint32_t nodes, prims;
+};
 
 // src/hittable/geometry.rs:36-57 — sphere quadratic in f64, evaluated in the reference's operation order
 // with contraction off so that `t` is bit-identical to the CPU path for identical inputs.
-// Returns true and updates tmax/best when a root lies in (tmin, tmax) exclusive.
 #pragma clang fp contract(off)
-__device__ __forceinline__ bool sphere_hit(const Prim& P, bool moving, d3 o, d3 d, double a, double time, double tmin,
-                                           double tmax, double& t_out) {
-  d3 c;
-  if (moving) {  // geometry.rs:108: center*(1-time) + destination*time
+__device__ __forceinline__ d3 sphere_center(const PrimGeom& g, double time) {
+  if (g.type == 1u) {  // geometry.rs:108: center*(1-time) + destination*time
     double w0 = 1. - time;
-    c = {P.f[0] * w0 + P.f[3] * time, P.f[1] * w0 + P.f[4] * time, P.f[2] * w0 + P.f[5] * time};
-  } else {
-    c = {P.f[0], P.f[1], P.f[2]};
+    return {g.c0.x * w0 + g.c1.x * time, g.c0.y * w0 + g.c1.y * time, g.c0.z * w0 + g.c1.z * time};
   }
-  double r = P.f[6];
+  return g.c0;
+}
+__device__ __forceinline__ bool sphere_hit(const PrimGeom& g, d3 o, d3 d, double a, double time, double tmin,
+                                           double tmax, double& t_out) {
+  d3 c = sphere_center(g, time);
+  double r = g.r;
   d3 oc = o - c;
   double alignment = oc.x * d.x + oc.y * d.y + oc.z * d.z;
   double surface = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - r * r;
@@ -166,8 +230,7 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
   d3 p = {o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
   d3 ph = {p.x - P.f[0], p.y - P.f[1], p.z - P.f[2]};
   d3 u = {P.f[3], P.f[4], P.f[5]}, v = {P.f[6], P.f[7], P.f[8]};
-  // w = n_raw / (n_raw . n_raw) = unit_n * inv_len
-  d3 w = {n.x * P.f[13], n.y * P.f[13], n.z * P.f[13]};
+  d3 w = {n.x * P.f[13], n.y * P.f[13], n.z * P.f[13]};  // n_raw / (n_raw . n_raw)
   d3 phxv = {ph.y * v.z - ph.z * v.y, ph.z * v.x - ph.x * v.z, ph.x * v.y - ph.y * v.x};
   d3 uxph = {u.y * ph.z - u.z * ph.y, u.z * ph.x - u.x * ph.z, u.x * ph.y - u.y * ph.x};
   double alpha = w.x * phxv.x + w.y * phxv.y + w.z * phxv.z;
@@ -180,13 +243,13 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
 #pragma clang fp contract(fast)
 
 // Per-ray constants of the f32 slab test.  t = plane*inv - (o*inv); the origin's f32 rounding error
-// |o|*2^-24*|inv| is covered by widening o*inv per axis (oiN for entry planes, oiF for exit planes); the box
-// coordinates' own rounding is covered by padding at build time.
+// |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
+// coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
 struct SlabRay {
-  float ix, iy, iz;        // 1/d
-  float nx, ny, nz;        // o*inv + slack   (subtracted from entry planes)
-  float fx, fy, fz;        // o*inv - slack   (subtracted from exit planes)
-  bool sx, sy, sz;         // direction negative on axis
+  float ix, iy, iz;
+  float nx, ny, nz;
+  float fx, fy, fz;
+  bool sx, sy, sz;  // direction negative on axis
 };
 __device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
   SlabRay s;
@@ -202,75 +265,95 @@ __device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
   s.sx = s.ix < 0.f; s.sy = s.iy < 0.f; s.sz = s.iz < 0.f;
   return s;
 }
-// returns entry distance (clamped to 0) in tn; hit iff tn <= tf
-__device__ __forceinline__ bool slab_test(const SlabRay& s, const float* lo, const float* hi, float tmax, float& tn) {
-  float nx = s.sx ? hi[0] : lo[0], fx = s.sx ? lo[0] : hi[0];
-  float ny = s.sy ? hi[1] : lo[1], fy = s.sy ? lo[1] : hi[1];
-  float nz = s.sz ? hi[2] : lo[2], fz = s.sz ? lo[2] : hi[2];
+// entry distance (clamped to 0) in tn; hit iff tn <= tf (widened)
+__device__ __forceinline__ bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hix, float hiy,
+                                          float hiz, float tmax, float& tn) {
+  float nx = s.sx ? hix : lox, fx = s.sx ? lox : hix;
+  float ny = s.sy ? hiy : loy, fy = s.sy ? loy : hiy;
+  float nz = s.sz ? hiz : loz, fz = s.sz ? loz : hiz;
   float t0x = __builtin_fmaf(nx, s.ix, -s.nx), t1x = __builtin_fmaf(fx, s.ix, -s.fx);
   float t0y = __builtin_fmaf(ny, s.iy, -s.ny), t1y = __builtin_fmaf(fy, s.iy, -s.fy);
   float t0z = __builtin_fmaf(nz, s.iz, -s.nz), t1z = __builtin_fmaf(fz, s.iz, -s.fz);
   // fmaxf/fminf ignore NaN (0*inf axes) => conservative
   tn = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), 0.f);
   float tf = fminf(fminf(fminf(t1x, t1y), t1z), tmax);
-  // relative widening of the far side covers the entry/exit rounding of near-degenerate intervals
   return tn <= tf * 1.0000019f + 1e-30f;
 }
 
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
-// stack (entries `stride` words apart => bank-conflict free).  Replaces BVHNode::hit / HittableList::hit
-// (src/hittable/containers.rs:29-40,177-191) + AABB::hit (src/hittable/aabb.rs:48-71).
-__device__ __forceinline__ HitInfo traverse(const Scene& sc, d3 o, d3 d, double time, double tmin, uint32_t* stack,
-                                            int stride) {
+// stack (entries `stride` elements apart => bank-conflict free).  "while-while" form: lanes walk inner
+// nodes until they hold a leaf, then the wave runs the (expensive, f64) leaf test together.
+// Replaces BVHNode::hit / HittableList::hit (src/hittable/containers.rs:29-40,177-191) + AABB::hit
+// (src/hittable/aabb.rs:48-71) + Sphere/MovingSphere::hit (geometry.rs:36-110).
+template <class Acc, class StackT, bool COUNT>
+__device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
+                                            double tmin, StackT* stack, int stride, TravCounters* cnt) {
   HitInfo best;
   best.t = __builtin_inf();
   best.prim = -1;
   const double a = d.x * d.x + d.y * d.y + d.z * d.z;  // squared_raydir_magnitude (geometry.rs:43)
-  SlabRay s = make_slab(o, d);
+  const SlabRay s = make_slab(o, d);
   float tmax32 = __builtin_inff();
   int sp = 0;
-  int32_t cur = sc.root;
-  while (true) {
-    if (cur >= 0) {
-      const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-      float4 q0 = np[0], q1 = np[1], q2 = np[2];
-      int2 ch = *reinterpret_cast<const int2*>(&np[3]);
-      float llo[3] = {q0.x, q0.y, q0.z}, lhi[3] = {q0.w, q1.x, q1.y};
-      float rlo[3] = {q1.z, q1.w, q2.x}, rhi[3] = {q2.y, q2.z, q2.w};
+  int32_t cur = root;
+  const int32_t DONE = RT_EMPTY_CHILD;
+  while (cur != DONE) {
+    // ---- inner nodes
+    while (cur >= 0) {
+      float4 q0, q1, q2;
+      int2 ch;
+      acc.node(cur, q0, q1, q2, ch);
+      if (COUNT) cnt->nodes++;
       float tl, tr;
-      bool hl = slab_test(s, llo, lhi, tmax32, tl);
-      bool hr = slab_test(s, rlo, rhi, tmax32, tr);
+      bool hl = slab_test(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax32, tl);
+      bool hr = slab_test(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax32, tr);
       if (hl && hr) {
         bool left_first = tl <= tr;
         int32_t nearc = left_first ? ch.x : ch.y, farc = left_first ? ch.y : ch.x;
-        stack[sp * stride] = (uint32_t)farc;
+        stack[sp * stride] = (StackT)farc;
         sp++;
         cur = nearc;
-        continue;
       } else if (hl) {
         cur = ch.x;
-        continue;
       } else if (hr) {
         cur = ch.y;
-        continue;
+      } else if (sp > 0) {
+        sp--;
+        cur = (int32_t)stack[sp * stride];
+      } else {
+        cur = DONE;
       }
-    } else if (cur != RT_EMPTY_CHILD) {
+    }
+    // ---- leaf
+    if (cur != DONE) {
       const int32_t pi = ~cur;
-      const Prim& P = sc.prims[pi];
+      if (COUNT) cnt->prims++;
       double t;
       bool h = false;
-      uint32_t ty = P.type;
-      if (ty <= 1u) h = sphere_hit(P, ty == 1u, o, d, a, time, tmin, best.t, t);
-      else if (ty == 2u) h = quad_hit(P, o, d, tmin, best.t, t);
+      if (Acc::kSpheresOnly) {
+        PrimGeom g = acc.sphere(pi);
+        h = sphere_hit(g, o, d, a, time, tmin, best.t, t);
+      } else {
+        uint32_t ty = acc.type(pi);
+        if (ty <= 1u) {
+          PrimGeom g = acc.sphere(pi);
+          h = sphere_hit(g, o, d, a, time, tmin, best.t, t);
+        } else if ((features & RT_F_QUAD) && ty == 2u) {
+          h = quad_hit(acc.full(pi), o, d, tmin, best.t, t);
+        }
+      }
       if (h) {
         best.t = t;
         best.prim = pi;
         tmax32 = __double2float_ru(t);
       }
+      if (sp > 0) {
+        sp--;
+        cur = (int32_t)stack[sp * stride];
+      } else {
+        cur = DONE;
+      }
     }
-    if (sp == 0) break;
-    sp--;
-    cur = (int32_t)stack[sp * stride];
   }
   return best;
 }
@@ -290,25 +373,21 @@ __device__ __forceinline__ void sphere_uv(d3 on, double& u, double& v) {  // geo
   u = phi / (2. * PI);
   v = theta / PI;
 }
-__device__ __forceinline__ HitRec make_hit(const Prim& P, d3 o, d3 d, double time, double t, bool want_uv) {
+template <class Acc>
+__device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 d, double time, double t, bool want_uv) {
   HitRec h;
   h.p = {o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};  // ray.at (ray.rs:17-19)
   h.u = 0; h.v = 0; h.uv_valid = false;
-  if (P.type <= 1u) {
-    d3 c;
-    if (P.type == 1u) {
-      double w0 = 1. - time;
-      c = {P.f[0] * w0 + P.f[3] * time, P.f[1] * w0 + P.f[4] * time, P.f[2] * w0 + P.f[5] * time};
-    } else {
-      c = {P.f[0], P.f[1], P.f[2]};
-    }
-    double r = P.f[6];
-    h.outward = {(h.p.x - c.x) / r, (h.p.y - c.y) / r, (h.p.z - c.z) / r};
+  if (Acc::kSpheresOnly || acc.type(pi) <= 1u) {
+    PrimGeom g = acc.sphere(pi);
+    d3 c = sphere_center(g, time);
+    h.outward = {(h.p.x - c.x) / g.r, (h.p.y - c.y) / g.r, (h.p.z - c.z) / g.r};
     if (want_uv) { sphere_uv(h.outward, h.u, h.v); h.uv_valid = true; }
   } else {
+    const Prim& P = acc.full(pi);
     h.outward = {P.f[9], P.f[10], P.f[11]};
     if (want_uv) {
-      double ab[2], tt;
+      double ab[2] = {0, 0}, tt;
       quad_hit(P, o, d, -__builtin_inf(), __builtin_inf(), tt, ab);
       h.u = ab[0]; h.v = ab[1]; h.uv_valid = true;
     }
@@ -322,8 +401,8 @@ __device__ __forceinline__ HitRec make_hit(const Prim& P, d3 o, d3 d, double tim
 
 // ----------------------------------------------------------------------------------------------- textures
 // xoroshiro128+ short jump as a GF(2)-linear map: state' = XOR over the 16 state bytes of table[byte][value]
-// (the jump of random.rs:37-57 is linear, so the 128 conditional XOR steps collapse to 16 lookups).
-__device__ __forceinline__ double noise_at_dev(const Scene& sc, int32_t x, int32_t y, int32_t z) {  // texture.rs:148-154
+// (the jump of random.rs:37-57 is linear, so its 128 conditional-XOR steps collapse to 16 table lookups).
+__device__ __noinline__ double noise_at_dev(const uint4* __restrict__ table, int32_t x, int32_t y, int32_t z) {  // texture.rs:148-154
   uint64_t a = (uint64_t)(int64_t)x;
   uint64_t b = (uint64_t)(int64_t)y + ((uint64_t)(int64_t)z << 32);
   uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
@@ -331,12 +410,12 @@ __device__ __forceinline__ double noise_at_dev(const Scene& sc, int32_t x, int32
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     uint32_t byte = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-    uint4 e = sc.noise_table[i * 256 + byte];
+    uint4 e = table[i * 256 + byte];
     acc.x ^= e.x; acc.y ^= e.y; acc.z ^= e.z; acc.w ^= e.w;
   }
   uint64_t s0 = (uint64_t)acc.x | ((uint64_t)acc.y << 32), s1 = (uint64_t)acc.z | ((uint64_t)acc.w << 32);
-  uint64_t r = s0 + s1;                            // next_u64 (random.rs:18-28)
-  return (double)r / 18446744073709551616.0;       // next_f64 (random.rs:30-32), u64->f64 RNE
+  uint64_t r = s0 + s1;                       // next_u64 (random.rs:18-28)
+  return (double)r / 18446744073709551616.0;  // next_f64 (random.rs:30-32), u64->f64 RNE
 }
 __device__ __forceinline__ int32_t sat_i32(double v) {  // Rust `as i32`
   if (!(v == v)) return 0;
@@ -345,16 +424,18 @@ __device__ __forceinline__ int32_t sat_i32(double v) {  // Rust `as i32`
   return (int32_t)v;
 }
 __device__ __forceinline__ double rem_euclid1(double a) {  // f64::rem_euclid(1.0)
-  double r = fmod(a, 1.0);
+  double r = a - trunc(a);  // == fmod(a, 1.0) exactly
   return r < 0.0 ? r + 1.0 : r;
 }
-__device__ __forceinline__ f3 tex_value(const Scene& sc, int32_t ti, const Prim& P, const HitRec& h0, d3 o, d3 d,
-                                        double time, double t) {
+template <uint32_t F, class Acc>
+__device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t ti, int32_t pi, const HitRec& h0, d3 o,
+                                        d3 d, double time, double t) {
   // texture.rs:55-66: a checker selects a child by the parity of floor(p*inv_scale); children may nest.
   for (int guard = 0; guard < 8; guard++) {
     const Texture& T = sc.texs[ti];
-    if (T.kind == 0u) return {T.rgb[0], T.rgb[1], T.rgb[2]};  // texture.rs:32-36
-    if (T.kind == 1u) {
+    const uint32_t kind = T.kind;
+    if (kind == 0u) return {T.rgb[0], T.rgb[1], T.rgb[2]};  // texture.rs:32-36
+    if ((F & RT_F_TEX_CHECKER) && kind == 1u) {
       int32_t x = sat_i32(floor(h0.p.x * T.inv_scale));
       int32_t y = sat_i32(floor(h0.p.y * T.inv_scale));
       int32_t z = sat_i32(floor(h0.p.z * T.inv_scale));
@@ -362,11 +443,11 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, int32_t ti, const Prim&
       ti = ((s & 1u) == 0u) ? T.odd : T.even;  // rem_euclid(2) == 0 -> `odd` field (texture.rs:60-61)
       continue;
     }
-    if (T.kind == 2u) {  // texture.rs:79-93
+    if ((F & RT_F_TEX_IMAGE) && kind == 2u) {  // texture.rs:79-93
       if (T.width == 0 || T.height == 0) return {0.f, 1.f, 1.f};
       double u = h0.u, v = h0.v;
       if (!h0.uv_valid) {
-        HitRec h = make_hit(P, o, d, time, t, true);
+        HitRec h = make_hit(acc, pi, o, d, time, t, true);
         u = h.u; v = h.v;
       }
       u = fmin(fmax(u, 0.0), 1.0);
@@ -378,20 +459,26 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, int32_t ti, const Prim&
       const float k = 1.0f / 255.0f;
       return {(float)(px & 0xffu) * k, (float)((px >> 8) & 0xffu) * k, (float)((px >> 16) & 0xffu) * k};
     }
-    // NOISE — texture.rs:108-146 (grey noise_at variant)
-    double x = h0.p.x * T.inv_scale, y = h0.p.y * T.inv_scale, z = h0.p.z * T.inv_scale;
-    int32_t ix = sat_i32(floor(x)), iy = sat_i32(floor(y)), iz = sat_i32(floor(z));
-    double fx = rem_euclid1(x), fy = rem_euclid1(y), fz = rem_euclid1(z);
-    double xb = fx * fx * (3.0 - 2.0 * fx), yb = fy * fy * (3.0 - 2.0 * fy), zb = fz * fz * (3.0 - 2.0 * fz);
-    int32_t ix1 = (int32_t)((uint32_t)ix + 1u), iy1 = (int32_t)((uint32_t)iy + 1u), iz1 = (int32_t)((uint32_t)iz + 1u);
-    auto lerp = [](double a, double b, double w) { return (1.0 - w) * a + w * b; };  // color.rs:62-64
-    double m00 = lerp(noise_at_dev(sc, ix, iy, iz), noise_at_dev(sc, ix1, iy, iz), xb);
-    double m01 = lerp(noise_at_dev(sc, ix, iy, iz1), noise_at_dev(sc, ix1, iy, iz1), xb);
-    double m10 = lerp(noise_at_dev(sc, ix, iy1, iz), noise_at_dev(sc, ix1, iy1, iz), xb);
-    double m11 = lerp(noise_at_dev(sc, ix, iy1, iz1), noise_at_dev(sc, ix1, iy1, iz1), xb);
-    double o0 = lerp(m00, m10, yb), o1 = lerp(m01, m11, yb);
-    float g = (float)lerp(o0, o1, zb);
-    return {g, g, g};
+    if ((F & RT_F_TEX_NOISE) && kind == 3u) {  // texture.rs:108-146 (grey noise_at variant)
+      double x = h0.p.x * T.inv_scale, y = h0.p.y * T.inv_scale, z = h0.p.z * T.inv_scale;
+      int32_t ix = sat_i32(floor(x)), iy = sat_i32(floor(y)), iz = sat_i32(floor(z));
+      double fx = rem_euclid1(x), fy = rem_euclid1(y), fz = rem_euclid1(z);
+      double xb = fx * fx * (3.0 - 2.0 * fx), yb = fy * fy * (3.0 - 2.0 * fy), zb = fz * fz * (3.0 - 2.0 * fz);
+      double c[8];
+      for (int k = 0; k < 8; k++) {  // corner k: x bit0, z bit1, y bit2 (order of texture.rs:130-137)
+        int32_t cx = (int32_t)((uint32_t)ix + (uint32_t)(k & 1));
+        int32_t cz = (int32_t)((uint32_t)iz + (uint32_t)((k >> 1) & 1));
+        int32_t cy = (int32_t)((uint32_t)iy + (uint32_t)((k >> 2) & 1));
+        c[k] = noise_at_dev(sc.noise_table, cx, cy, cz);
+      }
+      auto lerp = [](double a, double b, double w) { return (1.0 - w) * a + w * b; };  // color.rs:62-64
+      double m00 = lerp(c[0], c[1], xb), m01 = lerp(c[2], c[3], xb);
+      double m10 = lerp(c[4], c[5], xb), m11 = lerp(c[6], c[7], xb);
+      double o0 = lerp(m00, m10, yb), o1 = lerp(m01, m11, yb);
+      float g = (float)lerp(o0, o1, zb);
+      return {g, g, g};
+    }
+    break;
   }
   return {0.f, 1.f, 1.f};
 }
@@ -447,102 +534,85 @@ __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t pixel, 
 
 // ----------------------------------------------------------------------------------------------- shading
 struct ShadeOut {
-  bool alive;       // a scattered ray continues
-  f3 radiance;      // contribution when the path ends here (already multiplied by throughput)
-  bool terminated;  // path ended with a (possibly zero) contribution
-  d3 o, d;          // scattered ray
-  f3 thr;           // updated throughput
+  bool alive;   // a scattered ray continues (o, d, thr updated); otherwise `radiance` is the path's contribution
+  f3 radiance;  // already multiplied by the throughput
+  d3 o, d;
+  f3 thr;
 };
+__device__ __forceinline__ f3 sky(d3 d) {  // mod.rs:205-207
+  f3 u = normalize(tof(d));
+  float a = 0.5f * (u.y + 1.0f);
+  return {(1.f - a) + a * 0.5f, (1.f - a) + a * 0.7f, (1.f - a) + a * 1.0f};
+}
 
 // One bounce of ray_color_inner (src/camera/mod.rs:187-210) given the closest hit.
-__device__ __forceinline__ ShadeOut shade(const Scene& sc, const Camera& cam, d3 o, d3 d, double time, f3 thr,
-                                          HitInfo hit, uint32_t pixel, uint32_t s, uint32_t bounce, uint32_t k0,
+template <uint32_t F, class Acc>
+__device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const Camera& cam, d3 o, d3 d, double time,
+                                          f3 thr, HitInfo hit, uint32_t pixel, uint32_t s, uint32_t bounce, uint32_t k0,
                                           uint32_t k1) {
   ShadeOut out;
   out.alive = false;
-  out.terminated = true;
   out.radiance = {0.f, 0.f, 0.f};
   out.thr = thr;
   out.o = o; out.d = d;
-  if (hit.prim < 0) {  // miss: sky gradient (mod.rs:205-207) or solid background (EXT)
+  if (hit.prim < 0) {  // miss: sky gradient or solid background (EXT)
     f3 c;
-    if (cam.background_mode == 0u) {
-      f3 u = normalize(tof(d));
-      float a = 0.5f * (u.y + 1.0f);
-      c = {(1.f - a) + a * 0.5f, (1.f - a) + a * 0.7f, (1.f - a) + a * 1.0f};
-    } else {
-      c = {cam.background[0], cam.background[1], cam.background[2]};
-    }
+    if (cam.background_mode == 0u) c = sky(d);
+    else c = {cam.background[0], cam.background[1], cam.background[2]};
     out.radiance = {thr.x * c.x, thr.y * c.y, thr.z * c.z};
     return out;
   }
-  const Prim& P = sc.prims[hit.prim];
-  const Material& M = sc.mats[P.mat];
-  HitRec h = make_hit(P, o, d, time, hit.t, false);
+  const Material& M = sc.mats[acc.mat(hit.prim)];
+  const uint32_t kind = M.kind;
+  HitRec h = make_hit(acc, hit.prim, o, d, time, hit.t, false);
   uint32_t r[4];
   philox4x32_10(pixel, s, bounce, RT_RNG_SCATTER, k0, k1, r);
   f3 n = tof(h.n);
   f3 att, dir;
-  switch (M.kind) {
-    case 0u: {  // Lambertian (materials.rs:28-43)
-      f3 u = sample_unit_sphere(r[0], r[1]);
-      dir = n + u;
-      const float th = 1e-9f;
-      if (__builtin_fabsf(dir.x) < th && __builtin_fabsf(dir.y) < th && __builtin_fabsf(dir.z) < th) dir = n;
-      att = tex_value(sc, M.tex, P, h, o, d, time, hit.t);
-      break;
+  if (kind == 0u) {  // Lambertian (materials.rs:28-43)
+    f3 u = sample_unit_sphere(r[0], r[1]);
+    dir = n + u;
+    const float th = 1e-9f;
+    if (__builtin_fabsf(dir.x) < th && __builtin_fabsf(dir.y) < th && __builtin_fabsf(dir.z) < th) dir = n;
+    att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
+  } else if (kind == 1u) {  // Metal (materials.rs:73-80): reflects the UN-normalised direction, adds fuzz * unit
+    f3 df = tof(d);
+    f3 refl = df - (2.0f * dot(df, n)) * n;
+    f3 u = sample_unit_sphere(r[0], r[1]);
+    dir = refl + M.fuzz * u;
+    att = {M.albedo[0], M.albedo[1], M.albedo[2]};
+  } else if (kind == 2u) {  // Dielectric (materials.rs:104-141)
+    float ratio = h.front ? 1.0f / M.ior : M.ior;
+    f3 ud = normalize(tof(d));
+    float cos_t = fminf(-dot(ud, n), 1.0f);
+    float sin_t = __builtin_sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
+    bool cannot = ratio * sin_t > 1.0f;
+    float r0 = (1.f - ratio) / (1.f + ratio);
+    r0 = r0 * r0;
+    float m = 1.f - cos_t;
+    float refl_p = r0 + (1.f - r0) * (m * m * m * m * m);
+    if (cannot || refl_p > u01f(r[0])) {
+      dir = ud - (2.0f * dot(ud, n)) * n;
+    } else {  // refract (materials.rs:131-136)
+      f3 perp = ratio * (ud + cos_t * n);
+      float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp)));
+      dir = perp + par * n;
     }
-    case 1u: {  // Metal (materials.rs:73-80): reflects the UN-normalised direction, adds fuzz * unit
-      f3 df = tof(d);
-      f3 refl = df - (2.0f * dot(df, n)) * n;
-      f3 u = sample_unit_sphere(r[0], r[1]);
-      dir = refl + M.fuzz * u;
-      att = {M.albedo[0], M.albedo[1], M.albedo[2]};
-      break;
-    }
-    case 2u: {  // Dielectric (materials.rs:104-141)
-      float ratio = h.front ? 1.0f / M.ior : M.ior;
-      f3 ud = normalize(tof(d));
-      float cos_t = fminf(-dot(ud, n), 1.0f);
-      float sin_t = __builtin_sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
-      bool cannot = ratio * sin_t > 1.0f;
-      float r0 = (1.f - ratio) / (1.f + ratio);
-      r0 = r0 * r0;
-      float m = 1.f - cos_t;
-      float refl_p = r0 + (1.f - r0) * (m * m * m * m * m);
-      if (cannot || refl_p > u01f(r[0])) {
-        dir = ud - (2.0f * dot(ud, n)) * n;
-      } else {  // refract (materials.rs:131-136)
-        f3 perp = ratio * (ud + cos_t * n);
-        float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp)));
-        dir = perp + par * n;
-      }
-      att = {1.f, 1.f, 1.f};
-      break;
-    }
-    case 3u: {  // EXT diffuse light: emits, no scatter
-      f3 e = tex_value(sc, M.tex, P, h, o, d, time, hit.t);
-      // the reference integrator (background_mode 0) has no emission term
-      if (cam.background_mode != 0u) out.radiance = {thr.x * e.x, thr.y * e.y, thr.z * e.z};
-      else {
-        // a `None` scatter falls through to the sky in the reference (mod.rs:203-207)
-        f3 u = normalize(tof(d));
-        float a = 0.5f * (u.y + 1.0f);
-        out.radiance = {thr.x * ((1.f - a) + a * 0.5f), thr.y * ((1.f - a) + a * 0.7f), thr.z * ((1.f - a) + a)};
-      }
-      return out;
-    }
-    default: {  // EXT isotropic
-      dir = sample_unit_sphere(r[0], r[1]);
-      att = tex_value(sc, M.tex, P, h, o, d, time, hit.t);
-      break;
-    }
+    att = {1.f, 1.f, 1.f};
+  } else if (kind == 3u) {  // EXT diffuse light: emits, never scatters
+    f3 e;
+    if (cam.background_mode != 0u) e = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
+    else e = sky(d);  // reference integrator: a `None` scatter falls through to the sky (mod.rs:203-207)
+    out.radiance = {thr.x * e.x, thr.y * e.y, thr.z * e.z};
+    return out;
+  } else {  // EXT isotropic
+    dir = sample_unit_sphere(r[0], r[1]);
+    att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
   }
   out.thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
   out.o = h.p;
   out.d = tod(dir);
   out.alive = true;
-  out.terminated = false;
   return out;
 }
 

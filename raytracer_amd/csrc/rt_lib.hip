@@ -34,6 +34,12 @@ struct PassParams {
   uint32_t k0, k1;  // Philox key (seed)
 };
 
+__device__ __forceinline__ GlobalAcc global_acc(const Scene& sc) { return GlobalAcc{sc.nodes, sc.prims}; }
+__device__ __forceinline__ SphereAcc sphere_acc(const Scene& sc) {
+  return SphereAcc{reinterpret_cast<const float4*>(sc.nodes), sc.spheres, sc.prims};
+}
+
+// ------------------------------------------------------------------------------------------------ wavefront mode
 __global__ __launch_bounds__(RT_BLOCK) void k_generate(Camera cam, Queue q, float* __restrict__ Lr,
                                                        float* __restrict__ Lg, float* __restrict__ Lb, PassParams pp,
                                                        uint32_t* __restrict__ counts) {
@@ -54,22 +60,33 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Camera cam, Queue q, floa
   if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = pp.n_paths;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_intersect(Scene sc, Queue q, Hits h, const uint32_t* __restrict__ count) {
+template <bool SPHERES>
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect(Scene sc, uint32_t features, Queue q, Hits h,
+                                                        const uint32_t* __restrict__ count) {
   __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
   const uint32_t n = *count;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     d3 o = {q.ox[i], q.oy[i], q.oz[i]}, d = {q.dx[i], q.dy[i], q.dz[i]};
-    HitInfo hit = traverse(sc, o, d, q.time[i], RT_TMIN, stack + threadIdx.x, RT_BLOCK);
+    HitInfo hit;
+    if (SPHERES)
+      hit = traverse<SphereAcc, uint32_t, false>(sphere_acc(sc), sc.root, features, o, d, q.time[i], RT_TMIN,
+                                                 stack + threadIdx.x, RT_BLOCK, nullptr);
+    else
+      hit = traverse<GlobalAcc, uint32_t, false>(global_acc(sc), sc.root, features, o, d, q.time[i], RT_TMIN,
+                                                 stack + threadIdx.x, RT_BLOCK, nullptr);
     h.prim[i] = hit.prim;
     h.t[i] = hit.t;
   }
 }
 
 // wave64 compaction: ballot -> exclusive prefix via mbcnt -> one atomic per wave
+__device__ __forceinline__ uint32_t wave_prefix(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
   unsigned long long mask = __ballot(pred);
-  uint32_t lane_prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  uint32_t lane_prefix = wave_prefix(mask);
   uint32_t total = (uint32_t)__popcll(mask);
   uint32_t base = 0;
   if (total) {
@@ -80,6 +97,7 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
   return base + lane_prefix;
 }
 
+template <uint32_t F, bool SPHERES>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue qi, Hits h, Queue qo,
                                                     const uint32_t* __restrict__ count_in,
                                                     uint32_t* __restrict__ count_out, float* __restrict__ Lr,
@@ -104,8 +122,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue 
       hit.t = h.t[i];
       uint32_t pl = id / pp.S, k = id - pl * pp.S;
       uint32_t pixel = pp.pix0 + pl, s = pp.s_first + k * pp.s_stride;
-      so = shade(sc, cam, o, d, time, thr, hit, pixel, s, bounce, pp.k0, pp.k1);
-      if (so.terminated) {
+      if (SPHERES) so = shade<F>(sc, sphere_acc(sc), cam, o, d, time, thr, hit, pixel, s, bounce, pp.k0, pp.k1);
+      else so = shade<F>(sc, global_acc(sc), cam, o, d, time, thr, hit, pixel, s, bounce, pp.k0, pp.k1);
+      if (!so.alive) {
         Lr[id] = so.radiance.x; Lg[id] = so.radiance.y; Lb[id] = so.radiance.z;
       }
       // a ray scattered at the last allowed depth returns black (mod.rs:195-197): drop it, L stays 0
@@ -122,27 +141,181 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue 
   }
 }
 
-// fb[pixel] += sum_k L[pl*S + k]; also tallies the rays traced (sum of the per-bounce queue counts)
+// fb[pixel] += sum_k L[pl*S + k] (one wave per pixel: coalesced reads, DPP/shuffle reduction);
+// also tallies the rays traced (sum of the per-bounce queue counts)
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float* __restrict__ Lr, const float* __restrict__ Lg,
                                                          const float* __restrict__ Lb, float* __restrict__ fb,
                                                          PassParams pp, uint32_t n_pix_pass,
                                                          const uint32_t* __restrict__ counts, uint32_t n_counts,
                                                          unsigned long long* __restrict__ ray_total) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t pl = blockIdx.x * blockDim.x + threadIdx.x; pl < n_pix_pass; pl += stride) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t pl = wave; pl < n_pix_pass; pl += n_waves) {
     float r = 0.f, g = 0.f, b = 0.f;
     const size_t base = (size_t)pl * pp.S;
-    for (uint32_t k = 0; k < pp.S; k++) {
+    for (uint32_t k = lane; k < pp.S; k += 64) {
       r += Lr[base + k]; g += Lg[base + k]; b += Lb[base + k];
     }
-    const size_t p = (size_t)(pp.pix0 + pl) * 3;
-    fb[p] += r; fb[p + 1] += g; fb[p + 2] += b;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      r += __shfl_down(r, off, 64); g += __shfl_down(g, off, 64); b += __shfl_down(b, off, 64);
+    }
+    if (lane == 0) {
+      const size_t p = (size_t)(pp.pix0 + pl) * 3;
+      fb[p] += r; fb[p + 1] += g; fb[p + 2] += b;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     unsigned long long t = 0;
     for (uint32_t i = 0; i < n_counts; i++) t += counts[i];
     *ray_total += t;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ fused mode
+// One persistent kernel: every wave pulls work units (an 8x8-pixel tile x Ku sample indices) from a global
+// counter and runs generate -> (intersect -> shade)* for them with per-lane path regeneration: a lane whose path
+// ended takes the next sample of the unit's pool (wave64 ballot + prefix, no atomics), so lanes stay busy
+// regardless of path length.  Radiance is summed in per-wave LDS accumulators as 2^-40 fixed point (integer
+// adds are order-independent => bit-reproducible frames) and flushed to a u64 frame with global atomics.
+// No path state ever touches HBM.
+struct FusedParams {
+  uint32_t K, s_begin, s_stride, Ku;
+  uint32_t tiles_x, n_tiles, n_units;
+  uint32_t k0, k1;
+  uint32_t stack_depth;
+};
+#define RT_FIX_SCALE 1099511627776.0f  // 2^40
+
+enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2 };
+
+__device__ __forceinline__ unsigned long long to_fix(float v) {
+  if (!(v > 0.f)) return 0ull;  // also NaN
+  v = fminf(v, 1048576.0f);
+  return (unsigned long long)(v * RT_FIX_SCALE);
+}
+
+template <uint32_t F, int KIND, int BLOCK, class StackT>
+__global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
+                                                 unsigned long long* __restrict__ fbacc,
+                                                 unsigned long long* __restrict__ ray_total) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [accumulators][stack]
+  size_t off = 0;
+  float4* l_nodes = reinterpret_cast<float4*>(smem);
+  SphereRec* l_sph = nullptr;
+  if (KIND == KIND_SPHERES_LDS) {
+    off += (size_t)sc.n_nodes * 64;
+    l_sph = reinterpret_cast<SphereRec*>(smem + off);
+    off += (size_t)sc.n_prims * 64;
+    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
+    for (int i = threadIdx.x; i < sc.n_nodes * 4; i += BLOCK) l_nodes[i] = gn[i];
+    const float4* gs = reinterpret_cast<const float4*>(sc.spheres);
+    float4* ls = reinterpret_cast<float4*>(l_sph);
+    for (int i = threadIdx.x; i < sc.n_prims * 4; i += BLOCK) ls[i] = gs[i];
+  }
+  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
+  off += (size_t)(BLOCK / 64) * 192 * 8;
+  StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
+  if (KIND == KIND_SPHERES_LDS) __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long my_rays = 0;
+  while (true) {
+    uint32_t u = 0;
+    if (lane == 0) u = atomicAdd(unit_counter, 1u);
+    u = __shfl(u, 0, 64);
+    if (u >= fp.n_units) break;
+    const uint32_t tile = u % fp.n_tiles, chunk = u / fp.n_tiles;
+    const uint32_t x0 = (tile % fp.tiles_x) * 8, y0 = (tile / fp.tiles_x) * 8;
+    const uint32_t k_lo = chunk * fp.Ku;
+    const uint32_t k_n = min(fp.Ku, fp.K - k_lo);
+    const uint32_t total = 64u * k_n;
+    l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t next = 0;  // wave-uniform pool cursor
+    bool active = false;
+    d3 o = {0, 0, 0}, d = {0, 0, 0};
+    double time = 0;
+    f3 thr = {1.f, 1.f, 1.f};
+    uint32_t pixel = 0, s = 0, depth = 0, lpix = 0;
+    while (true) {
+      // ---- regenerate: lanes without a path take the next samples of the pool
+      unsigned long long need = __ballot(!active);
+      if (need && next < total) {
+        uint32_t j = next + wave_prefix(need);
+        if (!active && j < total) {
+          uint32_t pit = j & 63u, ks = j >> 6;
+          uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
+          if (px < cam.width && py < cam.height) {
+            pixel = py * cam.width + px;
+            s = fp.s_begin + (k_lo + ks) * fp.s_stride;
+            generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time);
+            thr = {1.f, 1.f, 1.f};
+            depth = 0;
+            lpix = pit;
+            active = true;
+          }
+        }
+        next = min(total, next + (uint32_t)__popcll(need));
+      }
+      if (__ballot(active) == 0ull) {
+        if (next >= total) break;
+        continue;
+      }
+      if (active) {
+        HitInfo hit;
+        ShadeOut so;
+        my_rays++;
+        if (KIND == KIND_SPHERES_LDS) {
+          SphereAccT<const SphereRec*> acc{l_nodes, l_sph, sc.prims};
+          hit = traverse<decltype(acc), StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
+          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+        } else if (KIND == KIND_SPHERES_GLOBAL) {
+          SphereAcc acc = sphere_acc(sc);
+          hit = traverse<SphereAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
+          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+        } else {
+          GlobalAcc acc = global_acc(sc);
+          hit = traverse<GlobalAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
+          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+        }
+        if (!so.alive) {
+          atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
+          atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
+          atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
+          active = false;
+        } else {
+          o = so.o; d = so.d; thr = so.thr;
+          depth++;
+          if (depth >= cam.max_depth) active = false;  // mod.rs:195-197: black
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {  // flush the tile's accumulators
+      uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
+      if (px < cam.width && py < cam.height) {
+        size_t p = ((size_t)py * cam.width + px) * 3;
+        unsigned long long a0 = l_acc[lane * 3], a1 = l_acc[lane * 3 + 1], a2 = l_acc[lane * 3 + 2];
+        if (a0) atomicAdd(&fbacc[p], a0);
+        if (a1) atomicAdd(&fbacc[p + 1], a1);
+        if (a2) atomicAdd(&fbacc[p + 2], a2);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // rays traced (stats): one atomic per wave
+  for (int off2 = 32; off2 > 0; off2 >>= 1) my_rays += __shfl_down(my_rays, off2, 64);
+  if (lane == 0 && my_rays) atomicAdd(ray_total, my_rays);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_fix_to_float(const unsigned long long* __restrict__ acc, float* __restrict__ fb,
+                                                           uint32_t n) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    fb[i] = (float)((double)acc[i] * 9.094947017729282e-13);  // 2^-40
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ sum, uint32_t n_values, double inv_spp,
@@ -161,22 +334,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
   }
 }
 
-// parity probe: closest hit + full hit record for caller-supplied f64 rays
-__global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, const rt_ray* __restrict__ rays, uint32_t n,
-                                                    rt_hit* __restrict__ out) {
+// parity probe: closest hit + full hit record for caller-supplied f64 rays (+ traversal counters)
+__global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features, const rt_ray* __restrict__ rays,
+                                                    uint32_t n, rt_hit* __restrict__ out,
+                                                    unsigned long long* __restrict__ trav_counters) {
   __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
   const uint32_t stride = gridDim.x * blockDim.x;
+  TravCounters tc = {0, 0};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
-    HitInfo hit = traverse(sc, o, d, r.time, RT_TMIN, stack + threadIdx.x, RT_BLOCK);
+    GlobalAcc acc = global_acc(sc);
+    HitInfo hit = traverse<GlobalAcc, uint32_t, true>(acc, sc.root, features, o, d, r.time, RT_TMIN,
+                                                      stack + threadIdx.x, RT_BLOCK, &tc);
     rt_hit ho;
     memset(&ho, 0, sizeof(ho));
     ho.object_id = -1;
     if (hit.prim >= 0) {
-      const Prim& P = sc.prims[hit.prim];
-      HitRec h = make_hit(P, o, d, r.time, hit.t, true);
-      ho.object_id = P.obj;
+      HitRec h = make_hit(acc, hit.prim, o, d, r.time, hit.t, true);
+      ho.object_id = sc.prims[hit.prim].obj;
       ho.front_face = h.front ? 1 : 0;
       ho.t = hit.t;
       ho.p[0] = h.p.x; ho.p[1] = h.p.y; ho.p[2] = h.p.z;
@@ -184,6 +360,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, const rt_ray* __re
       ho.u = h.u; ho.v = h.v;
     }
     out[i] = ho;
+  }
+  if (trav_counters) {
+    atomicAdd(&trav_counters[0], (unsigned long long)tc.nodes);
+    atomicAdd(&trav_counters[1], (unsigned long long)tc.prims);
   }
 }
 
@@ -195,8 +375,11 @@ struct rt_scene {
   Material* d_mats = nullptr;
   Texture* d_texs = nullptr;
   uint32_t* d_texels = nullptr;
+  SphereRec* d_spheres = nullptr;
   Scene view{};
   int bvh_depth = 0;
+  uint32_t features = 0;     // RT_F_* of what the scene contains
+  bool spheres_only = false;
 };
 
 struct WorkBuffers {
@@ -213,8 +396,15 @@ struct rt_ctx {
   std::string err;
   int64_t max_paths = 128ll << 20;
   int profile = 0;
-  int mode = 0;
+  int mode = 1;              // 0 = wavefront kernels, 1 = fused persistent kernel
+  int fused_ku = 0;          // samples per work unit (0 = auto)
+  int fused_lds = 1;         // keep the scene in LDS when it fits
   WorkBuffers wb;
+  uint32_t* d_unit_counter = nullptr;
+  unsigned long long* d_fbacc = nullptr;
+  size_t fbacc_cap = 0;
+  unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
+  unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
   size_t counts_cap = 0;
   unsigned long long* d_ray_total = nullptr;
@@ -294,6 +484,9 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_unit_counter, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(ctx->d_trav, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   // noise jump table: entry [byte position i][value v] = short_jump(state with only that byte set)
   std::vector<uint32_t> tab(16 * 256 * 4);
   for (int i = 0; i < 16; i++)
@@ -323,6 +516,9 @@ int rt_shutdown(rt_ctx* ctx) {
   free_work(ctx);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   if (ctx->d_ray_total) (void)hipFree(ctx->d_ray_total);
+  if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
+  if (ctx->d_fbacc) (void)hipFree(ctx->d_fbacc);
+  if (ctx->d_trav) (void)hipFree(ctx->d_trav);
   if (ctx->d_noise_table) (void)hipFree(ctx->d_noise_table);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -349,8 +545,13 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "profile") {
     ctx->profile = value ? 1 : 0;
   } else if (k == "mode") {
-    if (value != 0) return fail(ctx, RT_E_UNSUPPORTED, "mode: only 0 (wavefront) is implemented");
+    if (value != 0 && value != 1) return fail(ctx, RT_E_INVALID_ARG, "mode must be 0 (wavefront) or 1 (fused)");
     ctx->mode = (int)value;
+  } else if (k == "fused_ku") {
+    if (value < 0 || value > 65535) return fail(ctx, RT_E_INVALID_ARG, "fused_ku out of range");
+    ctx->fused_ku = (int)value;
+  } else if (k == "fused_lds") {
+    ctx->fused_lds = value ? 1 : 0;
   } else {
     return fail(ctx, RT_E_INVALID_ARG, "rt_set_option: unknown key " + k);
   }
@@ -395,6 +596,7 @@ int rt_scene_free(rt_ctx* ctx, rt_scene* s) {
   if (s->d_mats) (void)hipFree(s->d_mats);
   if (s->d_texs) (void)hipFree(s->d_texs);
   if (s->d_texels) (void)hipFree(s->d_texels);
+  if (s->d_spheres) (void)hipFree(s->d_spheres);
   delete s;
   return RT_OK;
 }
@@ -415,6 +617,13 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   }
   std::vector<Prim> prims(d->n_prims);
   std::vector<rtb::Box> boxes(d->n_prims);
+  sc->features = 0;
+  sc->spheres_only = true;
+  for (uint64_t i = 0; i < d->n_textures; i++) {
+    if (d->textures[i].kind == RT_TEX_CHECKER) sc->features |= RT_F_TEX_CHECKER;
+    if (d->textures[i].kind == RT_TEX_IMAGE) sc->features |= RT_F_TEX_IMAGE;
+    if (d->textures[i].kind == RT_TEX_NOISE) sc->features |= RT_F_TEX_NOISE;
+  }
   for (uint64_t i = 0; i < d->n_prims; i++) {
     const rt_prim& p = d->prims[i];
     Prim& q = prims[i];
@@ -440,6 +649,8 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       }
       q.f[6] = p.radius;
     } else if (p.type == RT_PRIM_QUAD) {
+      sc->features |= RT_F_QUAD;
+      sc->spheres_only = false;
       if (!finite3(p.a) || !finite3(p.b) || !finite3(p.c))
         return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": non-finite quad");
       const double *Q = p.a, *u = p.b, *v = p.c;
@@ -503,6 +714,21 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     HIP_TRY(ctx, hipMalloc(&sc->d_texels, (d->n_texel_bytes + 3) & ~3ull));
     HIP_TRY(ctx, hipMemcpy(sc->d_texels, d->texels, d->n_texel_bytes, hipMemcpyHostToDevice));
   }
+  if (sc->spheres_only) {
+    std::vector<SphereRec> recs(prims.size());
+    for (size_t i = 0; i < prims.size(); i++) {
+      SphereRec& r = recs[i];
+      memset(&r, 0, sizeof(r));
+      for (int a = 0; a < 3; a++) { r.c0[a] = prims[i].f[a]; r.c1[a] = prims[i].f[3 + a]; }
+      r.r = prims[i].f[6];
+      r.type = prims[i].type;
+      r.mat = prims[i].mat;
+    }
+    HIP_TRY(ctx, hipMalloc(&sc->d_spheres, recs.size() * sizeof(SphereRec)));
+    HIP_TRY(ctx, hipMemcpy(sc->d_spheres, recs.data(), recs.size() * sizeof(SphereRec), hipMemcpyHostToDevice));
+  }
+  sc->view.spheres = sc->d_spheres;
+  sc->view.bvh_depth = bvh.depth;
   sc->view.nodes = sc->d_nodes;
   sc->view.prims = sc->d_prims;
   sc->view.mats = sc->d_mats;
@@ -559,7 +785,9 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
     uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - off);
     uint32_t blocks = std::min<uint32_t>((m + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)ctx->n_cu * 8);
     if ((e = hipMemcpyAsync(d_rays, rays + off, (size_t)m * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
-    hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, d_rays, m, d_hits);
+    hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, scene->features, d_rays, m,
+                       d_hits, ctx->d_trav);
+    ctx->probe_rays += m;
     if ((e = hipGetLastError()) != hipSuccess) { rc = RT_E_HIP; break; }
     if ((e = hipMemcpyAsync(out_hits + off, d_hits, (size_t)m * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
@@ -644,6 +872,153 @@ struct StageTimer {
   }
 };
 
+}  // extern "C" (templates below need C++ linkage)
+
+// ---- wavefront mode: one kernel per stage per bounce, queues in HBM
+template <uint32_t F, bool SPH>
+static void launch_bounce(hipStream_t st, uint32_t blocks, const rt_scene* scene, const Camera& dc, rt_ctx* ctx, Queue& qi,
+                          Queue& qo, const PassParams& pp, uint32_t b, uint32_t depth, StageTimer& tm) {
+  tm.begin();
+  hipLaunchKernelGGL((k_intersect<SPH>), dim3(blocks), dim3(RT_BLOCK), 0, st, scene->view, scene->features, qi,
+                     ctx->wb.hits, ctx->d_counts + b);
+  tm.end(ctx->stats.ms_intersect);
+  tm.begin();
+  hipLaunchKernelGGL((k_shade<F, SPH>), dim3(blocks), dim3(RT_BLOCK), 0, st, scene->view, dc, qi, ctx->wb.hits, qo,
+                     ctx->d_counts + b, ctx->d_counts + b + 1, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb, pp, b,
+                     (uint32_t)(b + 1 == depth));
+  tm.end(ctx->stats.ms_shade);
+}
+
+static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const Camera& dc, uint64_t seed,
+                            uint32_t sample_begin, uint32_t sample_stride, uint32_t K, float* d_out_sum, hipStream_t st) {
+  const uint32_t n_pix = cam->width * cam->height;
+  // pass plan: all pixels x S samples when that fits max_paths, else pixel chunks x 1 sample
+  const uint64_t cap = (uint64_t)ctx->max_paths;
+  uint32_t pix_chunk = n_pix, S = K;
+  if ((uint64_t)n_pix * K > cap) {
+    if (n_pix <= cap) S = (uint32_t)std::max<uint64_t>(1, cap / n_pix);
+    else { S = 1; pix_chunk = (uint32_t)cap; }
+  }
+  int rc = ensure_work(ctx, (size_t)pix_chunk * S, cam->max_depth);
+  if (rc) return rc;
+  const uint32_t depth = cam->max_depth;
+  const uint32_t max_blocks = (uint32_t)ctx->n_cu * 8;
+  const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
+  StageTimer tm(ctx, st);
+  for (uint32_t pix0 = 0; pix0 < n_pix; pix0 += pix_chunk) {
+    const uint32_t npp = std::min(pix_chunk, n_pix - pix0);
+    for (uint32_t kk = 0; kk < K; kk += S) {
+      const uint32_t Sp = std::min(S, K - kk);
+      PassParams pp;
+      pp.n_paths = npp * Sp; pp.pix0 = pix0; pp.S = Sp;
+      pp.s_first = sample_begin + kk * sample_stride; pp.s_stride = sample_stride;
+      pp.k0 = (uint32_t)seed; pp.k1 = (uint32_t)(seed >> 32);
+      const uint32_t blocks = std::min<uint32_t>((pp.n_paths + RT_BLOCK - 1) / RT_BLOCK, max_blocks);
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)depth + 2) * 4, st));
+      tm.begin();
+      hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(RT_BLOCK), 0, st, dc, ctx->wb.q[0], ctx->wb.Lr, ctx->wb.Lg,
+                         ctx->wb.Lb, pp, ctx->d_counts);
+      tm.end(ctx->stats.ms_generate);
+      for (uint32_t b = 0; b < depth; b++) {
+        Queue& qi = ctx->wb.q[b & 1];
+        Queue& qo = ctx->wb.q[(b + 1) & 1];
+        if (scene->spheres_only && lean) launch_bounce<RT_F_TEX_CHECKER, true>(st, blocks, scene, dc, ctx, qi, qo, pp, b, depth, tm);
+        else if (scene->spheres_only) launch_bounce<RT_F_ALL, true>(st, blocks, scene, dc, ctx, qi, qo, pp, b, depth, tm);
+        else launch_bounce<RT_F_ALL, false>(st, blocks, scene, dc, ctx, qi, qo, pp, b, depth, tm);
+        ctx->stats.bounces_run++;
+        ctx->stats.intersect_launches++;
+      }
+      tm.begin();
+      const uint32_t ablocks = std::min<uint32_t>((npp + 3) / 4, max_blocks);
+      hipLaunchKernelGGL(k_accumulate, dim3(ablocks), dim3(RT_BLOCK), 0, st, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb,
+                         d_out_sum, pp, npp, ctx->d_counts, depth, ctx->d_ray_total);
+      tm.end(ctx->stats.ms_accumulate);
+      ctx->stats.passes++;
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+// ---- fused mode: one persistent kernel, no path state in HBM
+template <uint32_t F, int KIND, int BLOCK, class StackT>
+static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
+                        hipStream_t st) {
+  auto kern = k_fused<F, KIND, BLOCK, StackT>;
+  HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)smem));
+  int per_cu = 0;
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, smem));
+  if (per_cu < 1) return fail(ctx, RT_E_INTERNAL, "fused kernel does not fit on a CU");
+  const uint32_t waves = (uint32_t)ctx->n_cu * (uint32_t)per_cu * (BLOCK / 64);
+  FusedParams fp = fp0;
+  // work-unit size: ~24 units per resident wave for load balance, unless overridden
+  uint32_t chunks = 1;
+  if (ctx->fused_ku > 0) {
+    chunks = (fp.K + (uint32_t)ctx->fused_ku - 1) / (uint32_t)ctx->fused_ku;
+  } else {
+    uint64_t target = (uint64_t)waves * 24;
+    chunks = (uint32_t)std::min<uint64_t>(fp.K, std::max<uint64_t>(1, target / fp.n_tiles));
+  }
+  fp.Ku = (fp.K + chunks - 1) / chunks;
+  chunks = (fp.K + fp.Ku - 1) / fp.Ku;
+  fp.n_units = fp.n_tiles * chunks;
+  const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, dc, fp, ctx->d_unit_counter, ctx->d_fbacc,
+                     ctx->d_ray_total);
+  HIP_TRY(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const Camera& dc, uint64_t seed,
+                        uint32_t sample_begin, uint32_t sample_stride, uint32_t K, float* d_out_sum, hipStream_t st) {
+  const size_t n_val = (size_t)cam->width * cam->height * 3;
+  if (ctx->fbacc_cap < n_val) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_fbacc) (void)hipFree(ctx->d_fbacc);
+    ctx->d_fbacc = nullptr;
+    ctx->fbacc_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_fbacc, n_val * 8));
+    ctx->fbacc_cap = n_val;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_fbacc, 0, n_val * 8, st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), st));
+  FusedParams fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.K = K; fp.s_begin = sample_begin; fp.s_stride = sample_stride;
+  fp.tiles_x = (cam->width + 7) / 8;
+  fp.n_tiles = fp.tiles_x * ((cam->height + 7) / 8);
+  fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
+  const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
+  fp.stack_depth = sdepth;
+  const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
+  const bool small_ids = scene->view.n_nodes < 32000 && scene->view.n_prims < 32000;
+  int rc;
+  // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
+  const size_t lds_scene = (size_t)scene->view.n_nodes * 64 + (size_t)scene->view.n_prims * 64;
+  const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
+  StageTimer tm(ctx, st);
+  tm.begin();
+  if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
+    if (lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else rc = launch_fused<RT_F_ALL, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+  } else {
+    const size_t smem = 4 * 192 * 8 + (size_t)sdepth * 256 * 4;
+    if (scene->spheres_only && lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else if (scene->spheres_only) rc = launch_fused<RT_F_ALL, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+  }
+  if (rc) return rc;
+  tm.end(ctx->stats.ms_intersect);
+  const uint32_t blocks = std::min<uint32_t>((uint32_t)((n_val + RT_BLOCK - 1) / RT_BLOCK), (uint32_t)ctx->n_cu * 8);
+  hipLaunchKernelGGL(k_fix_to_float, dim3(blocks), dim3(RT_BLOCK), 0, st, ctx->d_fbacc, d_out_sum, (uint32_t)n_val);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->stats.passes = 1;
+  return RT_OK;
+}
+
+extern "C" {
+
 int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
                      uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
   if (!ctx) return RT_E_INVALID_ARG;
@@ -658,62 +1033,21 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
   const uint32_t n_pix = cam->width * cam->height;
   const uint32_t K = sample_begin < sample_end ? (sample_end - sample_begin + sample_stride - 1) / sample_stride : 0;
+  if (K > 65535u * 64u) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: too many samples per pixel in one call");
   ctx->stats = rt_stats();
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
-  HIP_TRY(ctx, hipMemsetAsync(d_out_sum, 0, (size_t)n_pix * 3 * sizeof(float), st));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ray_total, 0, sizeof(unsigned long long), st));
   if (K > 0 && cam->max_depth > 0) {
-    // pass plan: all pixels x S samples when that fits max_paths, else pixel chunks x 1 sample
-    const uint64_t cap = (uint64_t)ctx->max_paths;
-    uint32_t pix_chunk = n_pix, S = K;
-    if ((uint64_t)n_pix * K > cap) {
-      if (n_pix <= cap) S = (uint32_t)std::max<uint64_t>(1, cap / n_pix);
-      else { S = 1; pix_chunk = (uint32_t)cap; }
+    ctx->stats.paths = (uint64_t)n_pix * K;
+    if (ctx->mode == 0) {
+      HIP_TRY(ctx, hipMemsetAsync(d_out_sum, 0, (size_t)n_pix * 3 * sizeof(float), st));
+      rc = render_wavefront(ctx, scene, cam, dc, seed, sample_begin, sample_stride, K, d_out_sum, st);
+    } else {
+      rc = render_fused(ctx, scene, cam, dc, seed, sample_begin, sample_stride, K, d_out_sum, st);
     }
-    rc = ensure_work(ctx, (size_t)pix_chunk * S, cam->max_depth);
     if (rc) return rc;
-    const uint32_t depth = cam->max_depth;
-    const uint32_t max_blocks = (uint32_t)ctx->n_cu * 8;
-    StageTimer tm(ctx, st);
-    for (uint32_t pix0 = 0; pix0 < n_pix; pix0 += pix_chunk) {
-      const uint32_t npp = std::min(pix_chunk, n_pix - pix0);
-      for (uint32_t kk = 0; kk < K; kk += S) {
-        const uint32_t Sp = std::min(S, K - kk);
-        PassParams pp;
-        pp.n_paths = npp * Sp; pp.pix0 = pix0; pp.S = Sp;
-        pp.s_first = sample_begin + kk * sample_stride; pp.s_stride = sample_stride;
-        pp.k0 = (uint32_t)seed; pp.k1 = (uint32_t)(seed >> 32);
-        const uint32_t blocks = std::min<uint32_t>((pp.n_paths + RT_BLOCK - 1) / RT_BLOCK, max_blocks);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, ((size_t)depth + 2) * 4, st));
-        tm.begin();
-        hipLaunchKernelGGL(k_generate, dim3(blocks), dim3(RT_BLOCK), 0, st, dc, ctx->wb.q[0], ctx->wb.Lr, ctx->wb.Lg,
-                           ctx->wb.Lb, pp, ctx->d_counts);
-        tm.end(ctx->stats.ms_generate);
-        for (uint32_t b = 0; b < depth; b++) {
-          Queue& qi = ctx->wb.q[b & 1];
-          Queue& qo = ctx->wb.q[(b + 1) & 1];
-          tm.begin();
-          hipLaunchKernelGGL(k_intersect, dim3(blocks), dim3(RT_BLOCK), 0, st, scene->view, qi, ctx->wb.hits,
-                             ctx->d_counts + b);
-          tm.end(ctx->stats.ms_intersect);
-          tm.begin();
-          hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(RT_BLOCK), 0, st, scene->view, dc, qi, ctx->wb.hits, qo,
-                             ctx->d_counts + b, ctx->d_counts + b + 1, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb, pp, b,
-                             (uint32_t)(b + 1 == depth));
-          tm.end(ctx->stats.ms_shade);
-          ctx->stats.bounces_run++;
-          ctx->stats.intersect_launches++;
-        }
-        tm.begin();
-        const uint32_t ablocks = std::min<uint32_t>((npp + RT_BLOCK - 1) / RT_BLOCK, max_blocks);
-        hipLaunchKernelGGL(k_accumulate, dim3(ablocks), dim3(RT_BLOCK), 0, st, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb,
-                           d_out_sum, pp, npp, ctx->d_counts, depth, ctx->d_ray_total);
-        tm.end(ctx->stats.ms_accumulate);
-        ctx->stats.passes++;
-        ctx->stats.paths += pp.n_paths;
-      }
-    }
-    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    HIP_TRY(ctx, hipMemsetAsync(d_out_sum, 0, (size_t)n_pix * 3 * sizeof(float), st));
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
   ctx->timing_pending = true;
