@@ -152,6 +152,8 @@ typedef struct rt_stats {
   float ms_total;          /* hipEvent time of the whole render on the library's stream */
   float ms_generate, ms_intersect, ms_shade, ms_accumulate; /* per stage (only when profiling is enabled) */
   uint64_t intersect_launches;
+  uint64_t probe_rays, probe_node_visits, probe_prim_tests; /* rt_intersect traversal counters since rt_init */
+  float dbg[16]; /* "fused_stats" diagnostic build: lane-work / wave-trip tallies (nodes, leaves, shade, regen) */
 } rt_stats;
 
 /* ---- entry points --------------------------------------------------------------------------------------*/

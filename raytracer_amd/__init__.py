@@ -65,7 +65,9 @@ class RtCamera(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("passes", C.c_uint32), ("bounces_run", C.c_uint32),
                 ("ms_total", C.c_float), ("ms_generate", C.c_float), ("ms_intersect", C.c_float),
-                ("ms_shade", C.c_float), ("ms_accumulate", C.c_float), ("intersect_launches", C.c_uint64)]
+                ("ms_shade", C.c_float), ("ms_accumulate", C.c_float), ("intersect_launches", C.c_uint64),
+                ("probe_rays", C.c_uint64), ("probe_node_visits", C.c_uint64), ("probe_prim_tests", C.c_uint64),
+                ("dbg", C.c_float * 16)]
 
 
 RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("time", "<f8")])
@@ -175,7 +177,9 @@ class Context:
     def stats(self):
         s = RtStats()
         self.check(self.L.rt_get_stats(self.h, C.byref(s)))
-        return {f: getattr(s, f) for f, _ in RtStats._fields_}
+        d = {f: getattr(s, f) for f, _ in RtStats._fields_}
+        d["dbg"] = list(s.dbg)
+        return d
 
     def synchronize(self):
         self.check(self.L.rt_synchronize(self.h))

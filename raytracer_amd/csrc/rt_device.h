@@ -188,8 +188,12 @@ struct HitInfo {
   int32_t prim;  // -1 = miss
 };
 struct TravCounters {
-  uint32_t nodes, prims;
+  uint32_t nodes, prims;  // per-lane node steps / leaf tests
+  float wnodes, wprims;   // per-lane share of the wave's loop trips (sums to one per executed trip)
+  float t_nodes, t_prims; // per-lane share of the wave's cycles in the inner-node loop / leaf section
 };
+__device__ __forceinline__ uint64_t now_cycles() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ float wave_share() { return 1.0f / (float)__popcll(__ballot(1)); }
 
 // src/hittable/geometry.rs:36-57 — sphere quadratic in f64, evaluated in the reference's operation order
 // with contraction off so that `t` is bit-identical to the CPU path for identical inputs.
@@ -299,11 +303,13 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
   const int32_t DONE = RT_EMPTY_CHILD;
   while (cur != DONE) {
     // ---- inner nodes
+    uint64_t t0 = 0;
+    if (COUNT) t0 = now_cycles();
     while (cur >= 0) {
       float4 q0, q1, q2;
       int2 ch;
       acc.node(cur, q0, q1, q2, ch);
-      if (COUNT) cnt->nodes++;
+      if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
       float tl, tr;
       bool hl = slab_test(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax32, tl);
       bool hr = slab_test(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax32, tr);
@@ -324,10 +330,11 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
         cur = DONE;
       }
     }
+    if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
     // ---- leaf
     if (cur != DONE) {
       const int32_t pi = ~cur;
-      if (COUNT) cnt->prims++;
+      if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
       double t;
       bool h = false;
       if (Acc::kSpheresOnly) {
@@ -353,6 +360,7 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
       } else {
         cur = DONE;
       }
+      if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
     }
   }
   return best;

@@ -196,10 +196,14 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
   return (unsigned long long)(v * RT_FIX_SCALE);
 }
 
-template <uint32_t F, int KIND, int BLOCK, class StackT>
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
 __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
-                                                 unsigned long long* __restrict__ ray_total) {
+                                                 unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
+  uint64_t st_t0 = 0, st_tk = 0;
+  if (STATS) st_tk = now_cycles();
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [accumulators][stack]
   size_t off = 0;
@@ -243,12 +247,14 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
     while (true) {
       // ---- regenerate: lanes without a path take the next samples of the pool
       unsigned long long need = __ballot(!active);
+      if (STATS) st_t0 = now_cycles();
       if (need && next < total) {
         uint32_t j = next + wave_prefix(need);
         if (!active && j < total) {
           uint32_t pit = j & 63u, ks = j >> 6;
           uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
           if (px < cam.width && py < cam.height) {
+            if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
             pixel = py * cam.width + px;
             s = fp.s_begin + (k_lo + ks) * fp.s_stride;
             generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time);
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
         }
         next = min(total, next + (uint32_t)__popcll(need));
       }
+      if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
       if (__ballot(active) == 0ull) {
         if (next >= total) break;
         continue;
@@ -270,8 +277,10 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
         my_rays++;
         if (KIND == KIND_SPHERES_LDS) {
           SphereAccT<const SphereRec*> acc{l_nodes, l_sph, sc.prims};
-          hit = traverse<decltype(acc), StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
+          hit = traverse<decltype(acc), StackT, STATS>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, &tc);
+          if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
           so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+          if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
         } else if (KIND == KIND_SPHERES_GLOBAL) {
           SphereAcc acc = sphere_acc(sc);
           hit = traverse<SphereAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
@@ -309,6 +318,16 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
   // rays traced (stats): one atomic per wave
   for (int off2 = 32; off2 > 0; off2 >>= 1) my_rays += __shfl_down(my_rays, off2, 64);
   if (lane == 0 && my_rays) atomicAdd(ray_total, my_rays);
+  if (STATS && dbg) {  // diagnostic build only: lane-work vs wave-trip tallies per phase
+    st_ttotal = (float)(now_cycles() - st_tk) * (1.0f / 64.0f);
+    float v[13] = {(float)tc.nodes, tc.wnodes, (float)tc.prims, tc.wprims, st_shade, st_wshade, st_regen, st_wregen,
+                   tc.t_nodes, tc.t_prims, st_tshade, st_tregen, st_ttotal};
+    for (int k = 0; k < 13; k++) {
+      float x = v[k];
+      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
+      if (lane == 0) atomicAdd(&dbg[k], x);
+    }
+  }
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_fix_to_float(const unsigned long long* __restrict__ acc, float* __restrict__ fb,
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
                                                     unsigned long long* __restrict__ trav_counters) {
   __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
   const uint32_t stride = gridDim.x * blockDim.x;
-  TravCounters tc = {0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
@@ -399,6 +418,8 @@ struct rt_ctx {
   int mode = 1;              // 0 = wavefront kernels, 1 = fused persistent kernel
   int fused_ku = 0;          // samples per work unit (0 = auto)
   int fused_lds = 1;         // keep the scene in LDS when it fits
+  int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
+  float* d_dbg = nullptr;
   WorkBuffers wb;
   uint32_t* d_unit_counter = nullptr;
   unsigned long long* d_fbacc = nullptr;
@@ -486,6 +507,8 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_unit_counter, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(ctx->d_dbg, 0, 16 * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMemset(ctx->d_trav, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   // noise jump table: entry [byte position i][value v] = short_jump(state with only that byte set)
   std::vector<uint32_t> tab(16 * 256 * 4);
@@ -519,6 +542,7 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
   if (ctx->d_fbacc) (void)hipFree(ctx->d_fbacc);
   if (ctx->d_trav) (void)hipFree(ctx->d_trav);
+  if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_noise_table) (void)hipFree(ctx->d_noise_table);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -552,6 +576,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_ku = (int)value;
   } else if (k == "fused_lds") {
     ctx->fused_lds = value ? 1 : 0;
+  } else if (k == "fused_stats") {
+    ctx->fused_stats = value ? 1 : 0;
   } else {
     return fail(ctx, RT_E_INVALID_ARG, "rt_set_option: unknown key " + k);
   }
@@ -941,10 +967,10 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 }
 
 // ---- fused mode: one persistent kernel, no path state in HBM
-template <uint32_t F, int KIND, int BLOCK, class StackT>
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
-  auto kern = k_fused<F, KIND, BLOCK, StackT>;
+  auto kern = k_fused<F, KIND, BLOCK, StackT, STATS>;
   HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
   int per_cu = 0;
@@ -965,7 +991,7 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   fp.n_units = fp.n_tiles * chunks;
   const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, dc, fp, ctx->d_unit_counter, ctx->d_fbacc,
-                     ctx->d_ray_total);
+                     ctx->d_ray_total, ctx->d_dbg);
   HIP_TRY(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -1000,7 +1026,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   StageTimer tm(ctx, st);
   tm.begin();
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
-    if (lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    if (lean && ctx->fused_stats) {
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
+      rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true>(ctx, scene, dc, fp, lds_1024, st);
+    } else if (lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
     else rc = launch_fused<RT_F_ALL, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
   } else {
     const size_t smem = 4 * 192 * 8 + (size_t)sdepth * 256 * 4;
@@ -1084,6 +1113,12 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     unsigned long long rays = 0;
     HIP_TRY(ctx, hipMemcpy(&rays, ctx->d_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
     ctx->stats.rays = rays;
+    HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
+    unsigned long long trav[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpy(trav, ctx->d_trav, sizeof(trav), hipMemcpyDeviceToHost));
+    ctx->stats.probe_rays = ctx->probe_rays;
+    ctx->stats.probe_node_visits = trav[0];
+    ctx->stats.probe_prim_tests = trav[1];
     ctx->timing_pending = false;
   }
   *out = ctx->stats;
