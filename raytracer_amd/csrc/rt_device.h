@@ -41,18 +41,19 @@ struct __attribute__((aligned(64))) SphereRec {
 
 struct Material {  // 32 B
   uint32_t kind;
-  int32_t tex;
+  int32_t tex;  // texture index, or -1 when the texture is a solid colour inlined into `albedo` at upload
   float albedo[3];
   float fuzz, ior;
   uint32_t pad;
 };
-struct Texture {  // 48 B
+struct Texture {  // 64 B
   uint32_t kind;
-  int32_t odd, even;
+  int32_t odd, even;   // CHECKER children; -1 when the child is a solid colour inlined into rgb (odd) / rgb2 (even)
   uint32_t width, height;
   uint32_t texel_off;  // in texels (RGBA8 words)
-  float rgb[3];
-  uint32_t pad;
+  float rgb[3];        // SOLID colour, or the inlined `odd` child of a CHECKER
+  float rgb2[3];       // inlined `even` child of a CHECKER
+  uint32_t pad[2];
   double inv_scale;
 };
 
@@ -81,6 +82,7 @@ struct Queue {
   double *ox, *oy, *oz, *dx, *dy, *dz, *time;
   float *tr, *tg, *tb;
   uint32_t* id;  // pass-local path index: pixel_local * S + k
+  uint32_t *r0, *r1;  // per-path RNG state
 };
 struct Hits {
   int32_t* prim;
@@ -109,10 +111,23 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// purposes (counter word 3)
-#define RT_RNG_CAMERA 0x10000u   // subpixel x2, lens x2
-#define RT_RNG_CAMERA2 0x10001u  // time
-#define RT_RNG_SCATTER 0u        // counter word 2 is the bounce
+// Per-path stream: Philox (counter-based, keyed by pixel / sample / seed) is evaluated ONCE per path; two of its
+// words feed the lens sample and two seed a xoroshiro64** generator (Blackman & Vigna) that supplies the
+// path's remaining draws (time, sub-pixel jitter, scatter directions).  Streams of different (pixel, sample,
+// seed) are decorrelated by Philox; draws within a path cost ~10 integer ops instead of a 10-round Philox.
+struct PathRng {
+  uint32_t s0, s1;
+};
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+__device__ __forceinline__ uint32_t rng_next(PathRng& g) {
+  const uint32_t s0 = g.s0;
+  uint32_t s1 = g.s1;
+  const uint32_t r = rotl32(s0 * 0x9E3779BBu, 5) * 5u;
+  s1 ^= s0;
+  g.s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9);
+  g.s1 = rotl32(s1, 13);
+  return r;
+}
 
 __device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * 5.9604645e-8f + 2.9802322e-8f; }  // (0,1)
 __device__ __forceinline__ double u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
@@ -160,14 +175,16 @@ struct GlobalAcc {
   __device__ __forceinline__ const Prim& full(int32_t pi) const { return prims[pi]; }
   __device__ __forceinline__ uint32_t mat(int32_t pi) const { return prims[pi].mat; }
 };
-template <class SphT>  // SphT = const SphereRec* in global or LDS address space (inferred after inlining)
+// NSTRIDE = node stride in 16-byte units: 4 (dense, global memory) or 5 (LDS copy padded to 80 B so that the
+// per-lane random node fetches of a ds_read_b128 lane group spread over 16 bank offsets instead of 4).
+template <class SphT, int NSTRIDE = 4>  // SphT = const SphereRec* in global or LDS address space (inferred after inlining)
 struct SphereAccT {
   const float4* nodes;
   SphT spheres;
   const Prim* prims_unused;
   static constexpr bool kSpheresOnly = true;
   __device__ __forceinline__ void node(int32_t i, float4& q0, float4& q1, float4& q2, int2& ch) const {
-    const float4* np = nodes + 4 * i;
+    const float4* np = nodes + NSTRIDE * i;
     q0 = np[0]; q1 = np[1]; q2 = np[2];
     float4 q3 = np[3];
     ch = {__float_as_int(q3.x), __float_as_int(q3.y)};
@@ -205,8 +222,10 @@ __device__ __forceinline__ d3 sphere_center(const PrimGeom& g, double time) {
   }
   return g.c0;
 }
-__device__ __forceinline__ bool sphere_hit(const PrimGeom& g, d3 o, d3 d, double a, double time, double tmin,
-                                           double tmax, double& t_out) {
+// `inv_a` = 1/a is hoisted per ray: root = (-b -/+ sqrt(disc)) * inv_a differs from the reference's division by
+// at most one ulp (well inside the 1e-5 parity tolerance) and removes two f64 divisions per candidate.
+__device__ __forceinline__ bool sphere_hit(const PrimGeom& g, d3 o, d3 d, double a, double inv_a, double time,
+                                           double tmin, double tmax, double& t_out) {
   d3 c = sphere_center(g, time);
   double r = g.r;
   d3 oc = o - c;
@@ -215,9 +234,9 @@ __device__ __forceinline__ bool sphere_hit(const PrimGeom& g, d3 o, d3 d, double
   double disc = alignment * alignment - a * surface;
   if (disc < 0.) return false;
   double sq = __builtin_sqrt(disc);
-  double root = (-alignment - sq) / a;
+  double root = (-alignment - sq) * inv_a;
   if (!(tmin < root && root < tmax)) {
-    root = (-alignment + sq) / a;
+    root = (-alignment + sq) * inv_a;
     if (!(tmin < root && root < tmax)) return false;
   }
   t_out = root;
@@ -284,6 +303,96 @@ __device__ __forceinline__ bool slab_test(const SlabRay& s, float lox, float loy
   return tn <= tf * 1.0000019f + 1e-30f;
 }
 
+
+// Resumable traversal state: one ray's walk through the BVH can be advanced one inner-node step or one leaf test
+// at a time, so a wave can interleave lanes that are at different stages (k_fused's scheduler) or simply run it
+// to completion (traverse()).
+#define RT_DONE RT_EMPTY_CHILD
+struct TravState {
+  int32_t cur;  // >= 0 inner node, < 0 leaf (~prim), RT_DONE finished
+  int32_t sp;   // entries on the stack, INCLUDING the one cached in `top`
+  int32_t top;  // top-of-stack kept in a register: a pop never waits on LDS (its refill load overlaps the next step)
+  int32_t best_prim;
+  float tmax32;
+  double best_t;
+  double a, inv_a;  // |d|^2 (geometry.rs:43) and its reciprocal
+  SlabRay s;
+};
+// 1/x to ~1 ulp: hardware seed (v_rcp_f64) + two Newton steps; x is |d|^2 of a ray (normal range, > 0)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, d3 o, d3 d) {
+  ts.cur = root;
+  ts.sp = 0;
+  ts.top = RT_DONE;
+  ts.best_prim = -1;
+  ts.best_t = __builtin_inf();
+  ts.tmax32 = __builtin_inff();
+  ts.a = d.x * d.x + d.y * d.y + d.z * d.z;
+  ts.inv_a = fast_rcp(ts.a);
+  ts.s = make_slab(o, d);
+}
+template <class StackT>
+__device__ __forceinline__ void trav_push(TravState& ts, int32_t v, StackT* stack, int stride) {
+  if (ts.sp > 0) stack[(ts.sp - 1) * stride] = (StackT)ts.top;
+  ts.top = v;
+  ts.sp++;
+}
+template <class StackT>
+__device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int stride) {
+  ts.cur = ts.top;  // RT_DONE when the stack is empty
+  ts.top = RT_DONE;
+  if (ts.sp > 0) {
+    ts.sp--;
+    if (ts.sp > 0) ts.top = (int32_t)stack[(ts.sp - 1) * stride];
+  }
+}
+// precondition: ts.cur >= 0
+template <class Acc, class StackT>
+__device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT* stack, int stride) {
+  float4 q0, q1, q2;
+  int2 ch;
+  acc.node(ts.cur, q0, q1, q2, ch);
+  float tl, tr;
+  bool hl = slab_test(ts.s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ts.tmax32, tl);
+  bool hr = slab_test(ts.s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ts.tmax32, tr);
+  const bool left_first = tl <= tr;
+  const bool take_left = hl && (!hr || left_first);
+  if (hl && hr) trav_push(ts, left_first ? ch.y : ch.x, stack, stride);
+  if (hl || hr) ts.cur = take_left ? ch.x : ch.y;
+  else trav_pop(ts, stack, stride);
+}
+// precondition: ts.cur < 0 && ts.cur != RT_DONE
+template <class Acc, class StackT>
+__device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_t features, d3 o, d3 d, double time,
+                                          double tmin, StackT* stack, int stride) {
+  const int32_t pi = ~ts.cur;
+  double t;
+  bool h = false;
+  if (Acc::kSpheresOnly) {
+    PrimGeom g = acc.sphere(pi);
+    h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+  } else {
+    uint32_t ty = acc.type(pi);
+    if (ty <= 1u) {
+      PrimGeom g = acc.sphere(pi);
+      h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+    } else if ((features & RT_F_QUAD) && ty == 2u) {
+      h = quad_hit(acc.full(pi), o, d, tmin, ts.best_t, t);
+    }
+  }
+  if (h) {
+    ts.best_t = t;
+    ts.best_prim = pi;
+    ts.tmax32 = __double2float_ru(t);
+  }
+  trav_pop(ts, stack, stride);
+}
+
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
 // stack (entries `stride` elements apart => bank-conflict free).  "while-while" form: lanes walk inner
 // nodes until they hold a leaf, then the wave runs the (expensive, f64) leaf test together.
@@ -292,77 +401,25 @@ __device__ __forceinline__ bool slab_test(const SlabRay& s, float lox, float loy
 template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
                                             double tmin, StackT* stack, int stride, TravCounters* cnt) {
-  HitInfo best;
-  best.t = __builtin_inf();
-  best.prim = -1;
-  const double a = d.x * d.x + d.y * d.y + d.z * d.z;  // squared_raydir_magnitude (geometry.rs:43)
-  const SlabRay s = make_slab(o, d);
-  float tmax32 = __builtin_inff();
-  int sp = 0;
-  int32_t cur = root;
-  const int32_t DONE = RT_EMPTY_CHILD;
-  while (cur != DONE) {
-    // ---- inner nodes
+  TravState ts;
+  trav_init(ts, root, o, d);
+  while (ts.cur != RT_DONE) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();
-    while (cur >= 0) {
-      float4 q0, q1, q2;
-      int2 ch;
-      acc.node(cur, q0, q1, q2, ch);
+    while (ts.cur >= 0) {
       if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
-      float tl, tr;
-      bool hl = slab_test(s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tmax32, tl);
-      bool hr = slab_test(s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tmax32, tr);
-      if (hl && hr) {
-        bool left_first = tl <= tr;
-        int32_t nearc = left_first ? ch.x : ch.y, farc = left_first ? ch.y : ch.x;
-        stack[sp * stride] = (StackT)farc;
-        sp++;
-        cur = nearc;
-      } else if (hl) {
-        cur = ch.x;
-      } else if (hr) {
-        cur = ch.y;
-      } else if (sp > 0) {
-        sp--;
-        cur = (int32_t)stack[sp * stride];
-      } else {
-        cur = DONE;
-      }
+      node_step(acc, ts, stack, stride);
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
-    // ---- leaf
-    if (cur != DONE) {
-      const int32_t pi = ~cur;
+    if (ts.cur != RT_DONE) {
       if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
-      double t;
-      bool h = false;
-      if (Acc::kSpheresOnly) {
-        PrimGeom g = acc.sphere(pi);
-        h = sphere_hit(g, o, d, a, time, tmin, best.t, t);
-      } else {
-        uint32_t ty = acc.type(pi);
-        if (ty <= 1u) {
-          PrimGeom g = acc.sphere(pi);
-          h = sphere_hit(g, o, d, a, time, tmin, best.t, t);
-        } else if ((features & RT_F_QUAD) && ty == 2u) {
-          h = quad_hit(acc.full(pi), o, d, tmin, best.t, t);
-        }
-      }
-      if (h) {
-        best.t = t;
-        best.prim = pi;
-        tmax32 = __double2float_ru(t);
-      }
-      if (sp > 0) {
-        sp--;
-        cur = (int32_t)stack[sp * stride];
-      } else {
-        cur = DONE;
-      }
+      leaf_step(acc, ts, features, o, d, time, tmin, stack, stride);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
     }
   }
+  HitInfo best;
+  best.t = ts.best_t;
+  best.prim = ts.best_prim;
   return best;
 }
 
@@ -439,6 +496,7 @@ template <uint32_t F, class Acc>
 __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t ti, int32_t pi, const HitRec& h0, d3 o,
                                         d3 d, double time, double t) {
   // texture.rs:55-66: a checker selects a child by the parity of floor(p*inv_scale); children may nest.
+#pragma unroll 1
   for (int guard = 0; guard < 8; guard++) {
     const Texture& T = sc.texs[ti];
     const uint32_t kind = T.kind;
@@ -448,7 +506,9 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
       int32_t y = sat_i32(floor(h0.p.y * T.inv_scale));
       int32_t z = sat_i32(floor(h0.p.z * T.inv_scale));
       uint32_t s = (uint32_t)x + (uint32_t)y + (uint32_t)z;
-      ti = ((s & 1u) == 0u) ? T.odd : T.even;  // rem_euclid(2) == 0 -> `odd` field (texture.rs:60-61)
+      const bool is_odd = (s & 1u) == 0u;  // rem_euclid(2) == 0 -> `odd` field (texture.rs:60-61)
+      ti = is_odd ? T.odd : T.even;
+      if (ti < 0) return is_odd ? f3{T.rgb[0], T.rgb[1], T.rgb[2]} : f3{T.rgb2[0], T.rgb2[1], T.rgb2[2]};
       continue;
     }
     if ((F & RT_F_TEX_IMAGE) && kind == 2u) {  // texture.rs:79-93
@@ -503,10 +563,12 @@ __device__ __forceinline__ f3 sample_unit_sphere(uint32_t r0, uint32_t r1) {
 // Camera::sample_point (src/camera/mod.rs:176-186) + sample_pixel's sub-pixel position (mod.rs:150-172) for
 // sample index s of pixel (j = row, i = column).
 __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t pixel, uint32_t s, uint32_t k0, uint32_t k1,
-                                             d3& o, d3& d, double& time) {
+                                             d3& o, d3& d, double& time, PathRng& rng) {
   uint32_t j = pixel / cam.width, i = pixel - j * cam.width;
   uint32_t r[4];
-  philox4x32_10(pixel, s, 0u, RT_RNG_CAMERA, k0, k1, r);
+  philox4x32_10(pixel, s, 0u, 0u, k0, k1, r);
+  rng.s0 = r[2];
+  rng.s1 = r[3] | ((r[2] | r[3]) == 0u ? 1u : 0u);  // the all-zero state is a fixed point
   double dx, dy;
   {
 #pragma clang fp contract(off)
@@ -518,8 +580,8 @@ __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t pixel, 
       dy = (double)j + (double)yi * interval - offset;
       dx = (double)i + (double)xi * interval - offset;
     } else {  // Random(n): dy then dx uniform in [-0.5, 0.5) (mod.rs:166-167)
-      dy = (double)j + (u01d(r[0]) - 0.5);
-      dx = (double)i + (u01d(r[1]) - 0.5);
+      dy = (double)j + (u01d(rng_next(rng)) - 0.5);
+      dx = (double)i + (u01d(rng_next(rng)) - 0.5);
     }
     d3 pc = {cam.pixel00[0] + dx * cam.du[0] + dy * cam.dv[0], cam.pixel00[1] + dx * cam.du[1] + dy * cam.dv[1],
              cam.pixel00[2] + dx * cam.du[2] + dy * cam.dv[2]};
@@ -527,17 +589,15 @@ __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t pixel, 
       o = {cam.center[0], cam.center[1], cam.center[2]};
     } else {
       // uniform point in the unit disk (same distribution as the rejection loop of vec3.rs:48-59)
-      float rr = __builtin_sqrtf(u01f(r[2]));
-      float u = u01f(r[3]);
+      float rr = __builtin_sqrtf(u01f(r[0]));
+      float u = u01f(r[1]);
       double lx = (double)(rr * __builtin_amdgcn_cosf(u)), ly = (double)(rr * __builtin_amdgcn_sinf(u));
       o = {cam.center[0] + cam.dfu[0] * lx + cam.dfv[0] * ly, cam.center[1] + cam.dfu[1] * lx + cam.dfv[1] * ly,
            cam.center[2] + cam.dfu[2] * lx + cam.dfv[2] * ly};
     }
     d = {pc.x - o.x, pc.y - o.y, pc.z - o.z};
   }
-  uint32_t r2[4];
-  philox4x32_10(pixel, s, 0u, RT_RNG_CAMERA2, k0, k1, r2);
-  time = u01d(r2[0]);  // mod.rs:184
+  time = u01d(rng_next(rng));  // mod.rs:184
 }
 
 // ----------------------------------------------------------------------------------------------- shading
@@ -556,8 +616,7 @@ __device__ __forceinline__ f3 sky(d3 d) {  // mod.rs:205-207
 // One bounce of ray_color_inner (src/camera/mod.rs:187-210) given the closest hit.
 template <uint32_t F, class Acc>
 __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const Camera& cam, d3 o, d3 d, double time,
-                                          f3 thr, HitInfo hit, uint32_t pixel, uint32_t s, uint32_t bounce, uint32_t k0,
-                                          uint32_t k1) {
+                                          f3 thr, HitInfo hit, PathRng& rng) {
   ShadeOut out;
   out.alive = false;
   out.radiance = {0.f, 0.f, 0.f};
@@ -572,17 +631,31 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
   }
   const Material& M = sc.mats[acc.mat(hit.prim)];
   const uint32_t kind = M.kind;
-  HitRec h = make_hit(acc, hit.prim, o, d, time, hit.t, false);
-  uint32_t r[4];
-  philox4x32_10(pixel, s, bounce, RT_RNG_SCATTER, k0, k1, r);
-  f3 n = tof(h.n);
+  // hit record (geometry.rs:58-64): the point stays f64 (it is the next ray's origin); the normal is only ever
+  // used by f32 shading math, so it is formed from the f64 difference p - c scaled by an f32 reciprocal radius.
+  HitRec h;
+  h.p = {o.x + hit.t * d.x, o.y + hit.t * d.y, o.z + hit.t * d.z};
+  h.u = 0; h.v = 0; h.uv_valid = false;
+  f3 n;
+  if (Acc::kSpheresOnly || acc.type(hit.prim) <= 1u) {
+    PrimGeom g = acc.sphere(hit.prim);
+    d3 c = sphere_center(g, time);
+    n = __builtin_amdgcn_rcpf((float)g.r) * tof(h.p - c);
+  } else {
+    const Prim& P = acc.full(hit.prim);
+    n = {(float)P.f[9], (float)P.f[10], (float)P.f[11]};
+  }
+  h.front = dot(tof(d), n) < 0.f;
+  if (!h.front) n = -1.0f * n;
+  uint32_t r[2] = {rng_next(rng), rng_next(rng)};
   f3 att, dir;
   if (kind == 0u) {  // Lambertian (materials.rs:28-43)
     f3 u = sample_unit_sphere(r[0], r[1]);
     dir = n + u;
     const float th = 1e-9f;
     if (__builtin_fabsf(dir.x) < th && __builtin_fabsf(dir.y) < th && __builtin_fabsf(dir.z) < th) dir = n;
-    att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
+    if (M.tex < 0) att = {M.albedo[0], M.albedo[1], M.albedo[2]};
+    else att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
   } else if (kind == 1u) {  // Metal (materials.rs:73-80): reflects the UN-normalised direction, adds fuzz * unit
     f3 df = tof(d);
     f3 refl = df - (2.0f * dot(df, n)) * n;
@@ -609,13 +682,15 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
     att = {1.f, 1.f, 1.f};
   } else if (kind == 3u) {  // EXT diffuse light: emits, never scatters
     f3 e;
-    if (cam.background_mode != 0u) e = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
-    else e = sky(d);  // reference integrator: a `None` scatter falls through to the sky (mod.rs:203-207)
+    if (cam.background_mode == 0u) e = sky(d);
+    else if (M.tex < 0) e = {M.albedo[0], M.albedo[1], M.albedo[2]};
+    else e = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);  // reference integrator: a `None` scatter falls through to the sky (mod.rs:203-207)
     out.radiance = {thr.x * e.x, thr.y * e.y, thr.z * e.z};
     return out;
   } else {  // EXT isotropic
     dir = sample_unit_sphere(r[0], r[1]);
-    att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
+    if (M.tex < 0) att = {M.albedo[0], M.albedo[1], M.albedo[2]};
+    else att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
   }
   out.thr = {thr.x * att.x, thr.y * att.y, thr.z * att.z};
   out.o = h.p;

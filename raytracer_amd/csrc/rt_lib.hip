@@ -49,7 +49,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Camera cam, Queue q, floa
     uint32_t pixel = pp.pix0 + pl, s = pp.s_first + k * pp.s_stride;
     d3 o, d;
     double time;
-    generate_ray(cam, pixel, s, pp.k0, pp.k1, o, d, time);
+    PathRng rng;
+    generate_ray(cam, pixel, s, pp.k0, pp.k1, o, d, time, rng);
+    q.r0[i] = rng.s0; q.r1[i] = rng.s1;
     q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
     q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
     q.time[i] = time;
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue 
     ShadeOut so;
     uint32_t id = 0;
     double time = 0;
+    PathRng rng = {0, 0};
     if (i < n) {
       d3 o = {qi.ox[i], qi.oy[i], qi.oz[i]}, d = {qi.dx[i], qi.dy[i], qi.dz[i]};
       time = qi.time[i];
@@ -120,10 +123,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue 
       HitInfo hit;
       hit.prim = h.prim[i];
       hit.t = h.t[i];
-      uint32_t pl = id / pp.S, k = id - pl * pp.S;
-      uint32_t pixel = pp.pix0 + pl, s = pp.s_first + k * pp.s_stride;
-      if (SPHERES) so = shade<F>(sc, sphere_acc(sc), cam, o, d, time, thr, hit, pixel, s, bounce, pp.k0, pp.k1);
-      else so = shade<F>(sc, global_acc(sc), cam, o, d, time, thr, hit, pixel, s, bounce, pp.k0, pp.k1);
+      rng.s0 = qi.r0[i]; rng.s1 = qi.r1[i];
+      if (SPHERES) so = shade<F>(sc, sphere_acc(sc), cam, o, d, time, thr, hit, rng);
+      else so = shade<F>(sc, global_acc(sc), cam, o, d, time, thr, hit, rng);
       if (!so.alive) {
         Lr[id] = so.radiance.x; Lg[id] = so.radiance.y; Lb[id] = so.radiance.z;
       }
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(Scene sc, Camera cam, Queue 
       qo.time[slot] = time;
       qo.tr[slot] = so.thr.x; qo.tg[slot] = so.thr.y; qo.tb[slot] = so.thr.z;
       qo.id[slot] = id;
+      qo.r0[slot] = rng.s0; qo.r1[slot] = rng.s1;
     }
   }
 }
@@ -185,8 +188,10 @@ struct FusedParams {
   uint32_t tiles_x, n_tiles, n_units;
   uint32_t k0, k1;
   uint32_t stack_depth;
+  uint32_t kn, kl, ks;  // scheduler thresholds of k_fused_sched
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
+#define RT_LDS_NODE_STRIDE 5            // in 16-byte units (80 B), see SphereAccT
 
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2 };
 
@@ -210,11 +215,11 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
   float4* l_nodes = reinterpret_cast<float4*>(smem);
   SphereRec* l_sph = nullptr;
   if (KIND == KIND_SPHERES_LDS) {
-    off += (size_t)sc.n_nodes * 64;
+    off += (size_t)sc.n_nodes * RT_LDS_NODE_STRIDE * 16;
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
     off += (size_t)sc.n_prims * 64;
     const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
-    for (int i = threadIdx.x; i < sc.n_nodes * 4; i += BLOCK) l_nodes[i] = gn[i];
+    for (int i = threadIdx.x; i < sc.n_nodes * 4; i += BLOCK) l_nodes[(i >> 2) * RT_LDS_NODE_STRIDE + (i & 3)] = gn[i];
     const float4* gs = reinterpret_cast<const float4*>(sc.spheres);
     float4* ls = reinterpret_cast<float4*>(l_sph);
     for (int i = threadIdx.x; i < sc.n_prims * 4; i += BLOCK) ls[i] = gs[i];
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
     double time = 0;
     f3 thr = {1.f, 1.f, 1.f};
     uint32_t pixel = 0, s = 0, depth = 0, lpix = 0;
+    PathRng rng = {0, 0};
     while (true) {
       // ---- regenerate: lanes without a path take the next samples of the pool
       unsigned long long need = __ballot(!active);
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
             if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
             pixel = py * cam.width + px;
             s = fp.s_begin + (k_lo + ks) * fp.s_stride;
-            generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time);
+            generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
             thr = {1.f, 1.f, 1.f};
             depth = 0;
             lpix = pit;
@@ -276,19 +282,19 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
         ShadeOut so;
         my_rays++;
         if (KIND == KIND_SPHERES_LDS) {
-          SphereAccT<const SphereRec*> acc{l_nodes, l_sph, sc.prims};
+          SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE> acc{l_nodes, l_sph, sc.prims};
           hit = traverse<decltype(acc), StackT, STATS>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, &tc);
           if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
-          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
           if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
         } else if (KIND == KIND_SPHERES_GLOBAL) {
           SphereAcc acc = sphere_acc(sc);
           hit = traverse<SphereAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
-          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
         } else {
           GlobalAcc acc = global_acc(sc);
           hit = traverse<GlobalAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
-          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, pixel, s, depth, fp.k0, fp.k1);
+          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
         }
         if (!so.alive) {
           atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
@@ -324,6 +330,182 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
                    tc.t_nodes, tc.t_prims, st_tshade, st_tregen, st_ttotal};
     for (int k = 0; k < 13; k++) {
       float x = v[k];
+      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
+      if (lane == 0) atomicAdd(&dbg[k], x);
+    }
+  }
+}
+
+// ---- scheduled variant of the fused kernel -------------------------------------------------------------------
+// Same work units, pool, RNG streams and accumulators as k_fused, but the wave no longer runs
+// "traverse everything, then shade everything": every lane carries a resumable traversal (TravState) and the wave
+// picks, per iteration, the phase with enough waiting lanes — an inner-node step (N), a leaf test (L) or
+// shade + regenerate (S).  A lane whose traversal ends early is reshaded and re-launched while its neighbours
+// keep walking the tree, which is what lifts the SIMD lane utilisation of the node loop (profiles/: 32 % in
+// k_fused).  Thresholds kn / kl / ks are runtime parameters (FusedParams).
+template <int KIND> struct AccOf;
+template <> struct AccOf<KIND_SPHERES_LDS> {
+  using type = SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE>;
+  static __device__ __forceinline__ type make(const Scene& sc, const float4* ln, const SphereRec* ls) { return type{ln, ls, sc.prims}; }
+};
+template <> struct AccOf<KIND_SPHERES_GLOBAL> {
+  using type = SphereAcc;
+  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return sphere_acc(sc); }
+};
+template <> struct AccOf<KIND_GENERIC> {
+  using type = GlobalAcc;
+  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return global_acc(sc); }
+};
+
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
+__global__ __launch_bounds__(BLOCK) void k_fused_sched(Scene sc, Camera cam, FusedParams fp,
+                                                       uint32_t* __restrict__ unit_counter,
+                                                       unsigned long long* __restrict__ fbacc,
+                                                       unsigned long long* __restrict__ ray_total,
+                                                       float* __restrict__ dbg = nullptr) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  size_t off = 0;
+  float4* l_nodes = reinterpret_cast<float4*>(smem);
+  SphereRec* l_sph = nullptr;
+  if (KIND == KIND_SPHERES_LDS) {
+    off += (size_t)sc.n_nodes * RT_LDS_NODE_STRIDE * 16;
+    l_sph = reinterpret_cast<SphereRec*>(smem + off);
+    off += (size_t)sc.n_prims * 64;
+    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
+    for (int i = threadIdx.x; i < sc.n_nodes * 4; i += BLOCK) l_nodes[(i >> 2) * RT_LDS_NODE_STRIDE + (i & 3)] = gn[i];
+    const float4* gs = reinterpret_cast<const float4*>(sc.spheres);
+    float4* ls = reinterpret_cast<float4*>(l_sph);
+    for (int i = threadIdx.x; i < sc.n_prims * 4; i += BLOCK) ls[i] = gs[i];
+  }
+  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
+  off += (size_t)(BLOCK / 64) * 192 * 8;
+  StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
+  if (KIND == KIND_SPHERES_LDS) __syncthreads();
+  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph);
+
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t KN = fp.kn, KL = fp.kl, KS = fp.ks;
+  unsigned long long my_rays = 0;
+  float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // STATS: lane-work / wave-trips of N, L, S, R
+  while (true) {
+    uint32_t u = 0;
+    if (lane == 0) u = atomicAdd(unit_counter, 1u);
+    u = __shfl(u, 0, 64);
+    if (u >= fp.n_units) break;
+    const uint32_t tile = u % fp.n_tiles, chunk = u / fp.n_tiles;
+    const uint32_t x0 = (tile % fp.tiles_x) * 8, y0 = (tile / fp.tiles_x) * 8;
+    const uint32_t k_lo = chunk * fp.Ku;
+    const uint32_t k_n = min(fp.Ku, fp.K - k_lo);
+    const uint32_t total = 64u * k_n;
+    l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t next = 0;  // wave-uniform pool cursor
+    bool active = false;
+    d3 o = {0, 0, 0}, d = {0, 0, 0};
+    double time = 0;
+    f3 thr = {1.f, 1.f, 1.f};
+    uint32_t depth = 0, lpix = 0;
+    PathRng rng = {0, 0};
+    TravState ts;
+    ts.cur = RT_DONE; ts.sp = 0; ts.top = RT_DONE; ts.best_prim = -1; ts.tmax32 = 0.f; ts.best_t = 0; ts.a = 1; ts.inv_a = 1;
+    ts.s = SlabRay{0, 0, 0, 0, 0, 0, 0, 0, 0, false, false, false};
+    uint32_t kn_eff = KN;
+    while (true) {
+      // tight inner-node loop: keep stepping while enough lanes are walking the tree
+      uint32_t nN;
+      while (true) {
+        const bool inN = active && ts.cur >= 0;
+        nN = (uint32_t)__popcll(__ballot(inN));
+        if (nN < kn_eff) break;
+        if (inN) {
+          if (STATS) { st[0] += 1.f; st[1] += wave_share(); }
+          node_step(acc, ts, stack, BLOCK);
+        }
+      }
+      kn_eff = KN;
+      int act;  // 1 = leaf test, 2 = shade + regenerate
+      {
+        const bool inL = active && ts.cur < 0 && ts.cur != RT_DONE;
+        const uint32_t nL = (uint32_t)__popcll(__ballot(inL));
+        const uint32_t nS = (uint32_t)__popcll(__ballot(active && ts.cur == RT_DONE));
+        const uint32_t nR = min((uint32_t)__popcll(__ballot(!active)), total - next);
+        if (nL >= KL) act = 1;
+        else if (nS + nR >= KS) act = 2;
+        else if (nN > 0) { kn_eff = 1; continue; }  // not enough waiting work: keep walking with who is left
+        else if (nL > 0) act = 1;
+        else if (nS + nR > 0) act = 2;
+        else break;
+      }
+      if (act == 1) {
+        if (active && ts.cur < 0 && ts.cur != RT_DONE) {
+          if (STATS) { st[2] += 1.f; st[3] += wave_share(); }
+          leaf_step(acc, ts, F, o, d, time, RT_TMIN, stack, BLOCK);
+        }
+      } else {
+        if (active && ts.cur == RT_DONE) {
+          if (STATS) { st[4] += 1.f; st[5] += wave_share(); }
+          HitInfo hit;
+          hit.t = ts.best_t;
+          hit.prim = ts.best_prim;
+          ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
+          if (!so.alive) {
+            atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
+            atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
+            atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
+            active = false;
+          } else {
+            depth++;
+            if (depth >= cam.max_depth) {
+              active = false;  // mod.rs:195-197: black
+            } else {
+              o = so.o; d = so.d; thr = so.thr;
+              trav_init(ts, sc.root, o, d);
+              my_rays++;
+            }
+          }
+        }
+        // regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
+        unsigned long long need = __ballot(!active);
+        if (need && next < total) {
+          uint32_t j = next + wave_prefix(need);
+          if (!active && j < total) {
+            uint32_t pit = j & 63u, ks = j >> 6;
+            uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
+            if (px < cam.width && py < cam.height) {
+              if (STATS) { st[6] += 1.f; st[7] += wave_share(); }
+              uint32_t pixel = py * cam.width + px;
+              uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
+              generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
+              thr = {1.f, 1.f, 1.f};
+              depth = 0;
+              lpix = pit;
+              active = true;
+              trav_init(ts, sc.root, o, d);
+              my_rays++;
+            }
+          }
+          next = min(total, next + (uint32_t)__popcll(need));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {  // flush the tile's accumulators
+      uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
+      if (px < cam.width && py < cam.height) {
+        size_t p = ((size_t)py * cam.width + px) * 3;
+        unsigned long long a0 = l_acc[lane * 3], a1 = l_acc[lane * 3 + 1], a2 = l_acc[lane * 3 + 2];
+        if (a0) atomicAdd(&fbacc[p], a0);
+        if (a1) atomicAdd(&fbacc[p + 1], a1);
+        if (a2) atomicAdd(&fbacc[p + 2], a2);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int off2 = 32; off2 > 0; off2 >>= 1) my_rays += __shfl_down(my_rays, off2, 64);
+  if (lane == 0 && my_rays) atomicAdd(ray_total, my_rays);
+  if (STATS && dbg) {
+    for (int k = 0; k < 8; k++) {
+      float x = st[k];
       for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
       if (lane == 0) atomicAdd(&dbg[k], x);
     }
@@ -419,6 +601,9 @@ struct rt_ctx {
   int fused_ku = 0;          // samples per work unit (0 = auto)
   int fused_lds = 1;         // keep the scene in LDS when it fits
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
+  int fused_block = 1024;    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
+  int fused_sched = 0;       // 1 = k_fused_sched (phase scheduler), 0 = k_fused (bounce-synchronous)
+  int sched_kn = 24, sched_kl = 8, sched_ks = 24;
   float* d_dbg = nullptr;
   WorkBuffers wb;
   uint32_t* d_unit_counter = nullptr;
@@ -578,6 +763,14 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_lds = value ? 1 : 0;
   } else if (k == "fused_stats") {
     ctx->fused_stats = value ? 1 : 0;
+  } else if (k == "fused_block") {
+    if (value != 1024 && value != 512 && value != 256) return fail(ctx, RT_E_INVALID_ARG, "fused_block must be 1024, 512 or 256");
+    ctx->fused_block = (int)value;
+  } else if (k == "fused_sched") {
+    ctx->fused_sched = value ? 1 : 0;
+  } else if (k == "sched_kn" || k == "sched_kl" || k == "sched_ks") {
+    if (value < 1 || value > 64) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 1..64");
+    (k == "sched_kn" ? ctx->sched_kn : k == "sched_kl" ? ctx->sched_kl : ctx->sched_ks) = (int)value;
   } else {
     return fail(ctx, RT_E_INVALID_ARG, "rt_set_option: unknown key " + k);
   }
@@ -710,6 +903,11 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     for (int a = 0; a < 3; a++) o.albedo[a] = (float)m.albedo[a];
     o.fuzz = (float)m.fuzz;
     o.ior = (float)m.ior;
+    // inline solid-colour textures so the common case needs no texture fetch
+    if (m.tex >= 0 && d->textures[(size_t)m.tex].kind == RT_TEX_SOLID) {
+      for (int a = 0; a < 3; a++) o.albedo[a] = (float)d->textures[(size_t)m.tex].rgb[a];
+      o.tex = -1;
+    }
   }
   std::vector<Texture> texs(std::max<uint64_t>(d->n_textures, 1));
   memset(texs.data(), 0, texs.size() * sizeof(Texture));
@@ -724,6 +922,16 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     o.texel_off = (uint32_t)(t.texel_offset / 4);
     for (int a = 0; a < 3; a++) o.rgb[a] = (float)t.rgb[a];
     o.inv_scale = t.inv_scale;
+    if (t.kind == RT_TEX_CHECKER) {  // inline solid children (children precede their checker: validated above)
+      if (d->textures[(size_t)t.odd].kind == RT_TEX_SOLID) {
+        for (int a = 0; a < 3; a++) o.rgb[a] = (float)d->textures[(size_t)t.odd].rgb[a];
+        o.odd = -1;
+      }
+      if (d->textures[(size_t)t.even].kind == RT_TEX_SOLID) {
+        for (int a = 0; a < 3; a++) o.rgb2[a] = (float)d->textures[(size_t)t.even].rgb[a];
+        o.even = -1;
+      }
+    }
   }
   static_assert(sizeof(rtb::FlatNode) == sizeof(BvhNode), "node layout mismatch");
   size_t n_nodes = std::max<size_t>(bvh.nodes.size(), 1);
@@ -829,9 +1037,9 @@ static int ensure_work(rt_ctx* ctx, size_t cap, uint32_t depth) {
   if (ctx->wb.cap < cap) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_work(ctx);
-    // per path: 2 queues x (7 f64 + 3 f32 + 1 u32) + hits (i32 + f64) + L (3 f32)
+    // per path: 2 queues x (7 f64 + 3 f32 + 3 u32) + hits (i32 + f64) + L (3 f32)
     const size_t capa = (cap + 63) & ~(size_t)63;
-    const size_t per_q = capa * (7 * 8 + 3 * 4 + 4);
+    const size_t per_q = capa * (7 * 8 + 3 * 4 + 3 * 4);
     const size_t total = 2 * per_q + capa * (4 + 8) + capa * 12;
     HIP_TRY(ctx, hipMalloc(&ctx->wb.slab, total));
     char* p = (char*)ctx->wb.slab;
@@ -847,6 +1055,7 @@ static int ensure_work(rt_ctx* ctx, size_t cap, uint32_t depth) {
       Queue& q = ctx->wb.q[k];
       q.tr = (float*)take(capa * 4); q.tg = (float*)take(capa * 4); q.tb = (float*)take(capa * 4);
       q.id = (uint32_t*)take(capa * 4);
+      q.r0 = (uint32_t*)take(capa * 4); q.r1 = (uint32_t*)take(capa * 4);
     }
     ctx->wb.hits.prim = (int32_t*)take(capa * 4);
     ctx->wb.Lr = (float*)take(capa * 4); ctx->wb.Lg = (float*)take(capa * 4); ctx->wb.Lb = (float*)take(capa * 4);
@@ -970,7 +1179,7 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
-  auto kern = k_fused<F, KIND, BLOCK, StackT, STATS>;
+  auto kern = ctx->fused_sched ? k_fused_sched<F, KIND, BLOCK, StackT, STATS> : k_fused<F, KIND, BLOCK, StackT, STATS>;
   HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
   int per_cu = 0;
@@ -1017,11 +1226,12 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
+  fp.kn = (uint32_t)ctx->sched_kn; fp.kl = (uint32_t)ctx->sched_kl; fp.ks = (uint32_t)ctx->sched_ks;
   const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
   const bool small_ids = scene->view.n_nodes < 32000 && scene->view.n_prims < 32000;
   int rc;
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
-  const size_t lds_scene = (size_t)scene->view.n_nodes * 64 + (size_t)scene->view.n_prims * 64;
+  const size_t lds_scene = (size_t)scene->view.n_nodes * RT_LDS_NODE_STRIDE * 16 + (size_t)scene->view.n_prims * 64;
   const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   StageTimer tm(ctx, st);
   tm.begin();
@@ -1029,6 +1239,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     if (lean && ctx->fused_stats) {
       HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
       rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true>(ctx, scene, dc, fp, lds_1024, st);
+    } else if (lean && ctx->fused_block == 512) {
+      rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 512, int16_t>(ctx, scene, dc, fp, lds_scene + 8 * 192 * 8 + (size_t)sdepth * 512 * 2, st);
+    } else if (lean && ctx->fused_block == 256) {
+      rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 256, int16_t>(ctx, scene, dc, fp, lds_scene + 4 * 192 * 8 + (size_t)sdepth * 256 * 2, st);
     } else if (lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
     else rc = launch_fused<RT_F_ALL, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
   } else {

@@ -1,26 +1,49 @@
-"""Diagnostic: per-phase SIMD lane utilisation of the fused kernel (instrumented build, 'fused_stats')."""
+"""Diagnostic: per-phase SIMD lane utilisation of the fused kernels (instrumented build, 'fused_stats') and
+timing sweeps of the scheduler thresholds.   python scripts/fused_stats.py [spp] [--sweep]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 
 ctx = ra.Context(0)
-spp = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+spp = int(args[0]) if args else 100
 sc = ra.Scene("book_cover", 1200, 16 / 9, "uniform", spp, 50)
 dev = sc.upload(ctx)
 cam = sc.camera_copy()
-ctx.set_option("fused_stats", 1)
-for ku in ([int(a) for a in sys.argv[2:]] or [0]):
-    ctx.set_option("fused_ku", ku)
+
+
+def run(stats, **opts):
+    ctx.set_option("fused_stats", 1 if stats else 0)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
     dev.render_sums(cam, seed=1)
-    st = ctx.stats()
-    d = st["dbg"]
-    names = ["node", "leaf", "shade", "regen"]
-    out = {"ku": ku, "ms": st["ms_total"], "rays": st["rays"], "paths": st["paths"]}
-    for i, n in enumerate(names):
-        lane, wave = d[2 * i], d[2 * i + 1]
-        out[n] = {"per_ray": lane / st["rays"], "wave_trips_per_ray_x64": wave * 64 / st["rays"],
-                  "lane_util": lane / (64 * wave) if wave else None}
-    tot = d[12]
-    out["cycles_share"] = {"node": d[8] / tot, "leaf": d[9] / tot, "shade": d[10] / tot, "regen": d[11] / tot}
-    out["wave_cycles_per_trip"] = {"node": d[8] / d[1], "leaf": d[9] / d[3], "shade": d[10] / d[5], "regen": d[11] / d[7]}
-    print(json.dumps(out))
+    best = 1e9
+    for _ in range(1 if stats else 3):
+        dev.render_sums(cam, seed=1)
+        st = ctx.stats()
+        best = min(best, st["ms_total"])
+    out = dict(opts, ms=round(best, 3), msamples_s=round(st["paths"] / best / 1e3, 1))
+    if stats:
+        d = st["dbg"]
+        for i, n in enumerate(["node", "leaf", "shade", "regen"]):
+            lane, wave = d[2 * i], d[2 * i + 1]
+            out[n] = {"per_ray": round(lane / st["rays"], 3), "trips_x64_per_ray": round(wave * 64 / st["rays"], 3),
+                      "lane_util": round(lane / (64 * wave), 3) if wave else None}
+    print(json.dumps(out), flush=True)
+
+
+run(False, fused_sched=0)
+if "--occ" in sys.argv:
+    run(False, fused_sched=0, fused_block=512)
+    run(False, fused_sched=0, fused_block=256)
+    run(False, fused_sched=0, fused_block=1024, fused_lds=0)
+    ctx.set_option("fused_lds", 1)
+if "--stats" in sys.argv:
+    run(True, fused_sched=0)
+    run(False, fused_sched=1, sched_kn=24, sched_kl=8, sched_ks=24)
+    run(True, fused_sched=1, sched_kn=24, sched_kl=8, sched_ks=24)
+if "--sweep" in sys.argv:
+    for kn in (8, 16, 24, 32):
+        for kl in (8, 16, 24, 32):
+            for ks in (24, 32, 40, 48, 56):
+                run(False, fused_sched=1, sched_kn=kn, sched_kl=kl, sched_ks=ks)
