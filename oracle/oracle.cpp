@@ -1051,14 +1051,14 @@ struct WorldBuilder {
   }
 };
 // EXT: box = 6 quads (The Next Week §6.?), ids consecutive
-static std::unique_ptr<HittableList> make_box(Point3 a, Point3 b, std::shared_ptr<Material> m, int& next_id) {
+static std::unique_ptr<HittableList> make_box(Point3 a, Point3 b, std::shared_ptr<Material> m, int* next_id) {
   auto sides = std::make_unique<HittableList>();
   Point3 mn(std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z));
   Point3 mx(std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z));
   Vec3 dx(mx.x - mn.x, 0, 0), dy(0, mx.y - mn.y, 0), dz(0, 0, mx.z - mn.z);
   auto addq = [&](Point3 Q, Vec3 u, Vec3 v) {
     auto q = std::make_unique<Quad>(Q, u, v, m);
-    q->object_id = next_id++;
+    q->object_id = next_id ? (*next_id)++ : -1;
     sides->add(std::move(q));
   };
   addq(Point3(mn.x, mn.y, mx.z), dx, dy);    // front
@@ -1194,6 +1194,102 @@ static bool something_blocky(const SceneParams& p, Scene& sc, std::string& err) 
   return finish(sc, cb, into_bvh(std::move(w.list)), n, err);
 }
 
+// ---- EXT scenes (book scenes; not in the reference).  Object ids follow insertion order, boxes = 6 consecutive ids.
+static void cornell_walls(WorldBuilder& w) {
+  auto red = std::make_shared<Lambertian>(Color(.65, .05, .05));
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  auto green = std::make_shared<Lambertian>(Color(.12, .45, .15));
+  auto light = std::make_shared<DiffuseLight>(Color(7, 7, 7));
+  w.add_quad(Point3(555, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), green);
+  w.add_quad(Point3(0, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), red);
+  w.add_quad(Point3(113, 554, 127), Vec3(330, 0, 0), Vec3(0, 0, 305), light);
+  w.add_quad(Point3(0, 555, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white);
+  w.add_quad(Point3(0, 0, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white);
+  w.add_quad(Point3(0, 0, 555), Vec3(555, 0, 0), Vec3(0, 555, 0), white);
+}
+static CameraBuilder cornell_camera(const SceneParams& p) {
+  CameraBuilder cb = base_builder(p);
+  cb.background_mode = 1;
+  cb.background = Color(0, 0, 0);
+  cb.field_of_view = 40.0;
+  cb.lookfrom = Point3(278, 278, -800);
+  cb.lookat = Point3(278, 278, 0);
+  cb.up_vector = Vec3(0, 1, 0);
+  cb.defocus_angle = 0.0;
+  return cb;
+}
+static std::unique_ptr<Hittable> placed_box(Point3 b, double angle, Vec3 off, std::shared_ptr<Material> m, int* next_id) {
+  return std::make_unique<Translate>(std::make_unique<RotateY>(make_box(Point3(0, 0, 0), b, m, next_id), angle), off);
+}
+static bool cornell_box(const SceneParams& p, Scene& sc, std::string& err) {
+  CameraBuilder cb = cornell_camera(p);
+  WorldBuilder w;
+  cornell_walls(w);
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  w.list->add(placed_box(Point3(165, 330, 165), 15.0, Vec3(265, 0, 295), white, &w.next_id));
+  w.list->add(placed_box(Point3(165, 165, 165), -18.0, Vec3(130, 0, 65), white, &w.next_id));
+  int n = w.next_id;
+  return finish(sc, cb, into_bvh(std::move(w.list)), n, err);
+}
+static void add_medium(WorldBuilder& w, std::unique_ptr<Hittable> boundary, double density, Color albedo) {
+  auto m = std::make_unique<ConstantMedium>(std::move(boundary), density, albedo);
+  m->object_id = w.next_id++;
+  w.list->add(std::move(m));
+}
+static bool cornell_smoke(const SceneParams& p, Scene& sc, std::string& err) {
+  CameraBuilder cb = cornell_camera(p);
+  WorldBuilder w;
+  cornell_walls(w);
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  add_medium(w, placed_box(Point3(165, 330, 165), 15.0, Vec3(265, 0, 295), white, nullptr), 0.01, Color(0, 0, 0));
+  add_medium(w, placed_box(Point3(165, 165, 165), -18.0, Vec3(130, 0, 65), white, nullptr), 0.01, Color(1, 1, 1));
+  int n = w.next_id;
+  return finish(sc, cb, into_bvh(std::move(w.list)), n, err);
+}
+static bool final_scene(const SceneParams& p, const RgbaImage& img, int boxes_per_side, int cluster_spheres, Scene& sc,
+                        std::string& err) {
+  CameraBuilder cb = base_builder(p);
+  cb.background_mode = 1;
+  cb.background = Color(0, 0, 0);
+  cb.field_of_view = 40.0;
+  cb.lookfrom = Point3(478, 278, -600);
+  cb.lookat = Point3(278, 278, 0);
+  cb.up_vector = Vec3(0, 1, 0);
+  cb.defocus_angle = 0.0;
+  Rng rng(2024, 7);
+  WorldBuilder w;
+  auto ground = std::make_shared<Lambertian>(Color(0.48, 0.83, 0.53));
+  const double bw = 2000.0 / (double)boxes_per_side;
+  for (int i = 0; i < boxes_per_side; i++)
+    for (int j = 0; j < boxes_per_side; j++) {
+      double x0 = -1000.0 + i * bw, z0 = -1000.0 + j * bw, y0 = 0.0;
+      double x1 = x0 + bw, y1 = rng.next_f64_range(1.0, 101.0), z1 = z0 + bw;
+      w.list->add(make_box(Point3(x0, y0, z0), Point3(x1, y1, z1), ground, &w.next_id));
+    }
+  w.add_quad(Point3(123, 554, 147), Vec3(300, 0, 0), Vec3(0, 0, 265), std::make_shared<DiffuseLight>(Color(7, 7, 7)));
+  Point3 center1(400, 400, 200);
+  w.add_moving(center1, 50, std::make_shared<Lambertian>(Color(0.7, 0.3, 0.1)), center1 + Vec3(30, 0, 0));
+  w.add_sphere(Point3(260, 150, 45), 50, std::make_shared<Dielectric>(1.5));
+  w.add_sphere(Point3(0, 150, 145), 50, std::make_shared<Metal>(Color(0.8, 0.8, 0.9), 1.0));
+  w.add_sphere(Point3(360, 150, 145), 70, std::make_shared<Dielectric>(1.5));
+  add_medium(w, std::make_unique<Sphere>(Point3(360, 150, 145), 70, std::make_shared<Dielectric>(1.5)), 0.2,
+             Color(0.2, 0.4, 0.9));
+  add_medium(w, std::make_unique<Sphere>(Point3(0, 0, 0), 5000, std::make_shared<Dielectric>(1.5)), .0001, Color(1, 1, 1));
+  w.add_sphere(Point3(400, 200, 400), 100, std::make_shared<Lambertian>(std::make_shared<ImageTexture>(img)));
+  w.add_sphere(Point3(220, 280, 300), 80, std::make_shared<Lambertian>(std::make_shared<NoiseTexture>(0.2)));
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  auto cluster = std::make_unique<HittableList>();
+  for (int j = 0; j < cluster_spheres; j++) {
+    double x = rng.next_f64_range(0.0, 165.0), y = rng.next_f64_range(0.0, 165.0), z = rng.next_f64_range(0.0, 165.0);
+    auto sp = std::make_unique<Sphere>(Point3(x, y, z), 10, white);
+    sp->object_id = w.next_id++;
+    cluster->add(std::move(sp));
+  }
+  w.list->add(std::make_unique<Translate>(std::make_unique<RotateY>(into_bvh(std::move(cluster)), 15.0), Vec3(-100, 270, 395)));
+  int n = w.next_id;
+  return finish(sc, cb, into_bvh(std::move(w.list)), n, err);
+}
+
 }  // namespace orc
 
 // =================================================================== C facade (ctypes)
@@ -1248,10 +1344,14 @@ orc_scene* orc_scene_create(const char* name, uint64_t width, double aspect, int
   else if (n == "book_cover") ok = book_cover(p, h->sc, h->err);
   else if (n == "two_spheres") ok = two_spheres(p, h->sc, h->err);
   else if (n == "something_blocky") ok = something_blocky(p, h->sc, h->err);
-  else if (n == "earth") {
+  else if (n == "cornell_box") ok = cornell_box(p, h->sc, h->err);
+  else if (n == "cornell_smoke") ok = cornell_smoke(p, h->sc, h->err);
+  else if (n == "earth" || n == "final_scene" || n == "final_scene_small") {
     RgbaImage img;
     if (texels) { img.w = tw; img.h = th; img.data.assign(texels, texels + (size_t)4 * tw * th); }
-    ok = earth(p, img, h->sc, h->err);
+    if (n == "earth") ok = earth(p, img, h->sc, h->err);
+    else if (n == "final_scene") ok = final_scene(p, img, 20, 1000, h->sc, h->err);
+    else ok = final_scene(p, img, 6, 60, h->sc, h->err);
   } else h->err = "unknown scene: " + n;
   h->sc.name = n;
   if (!ok) h->sc.world.reset();

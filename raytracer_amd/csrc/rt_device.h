@@ -26,8 +26,8 @@ struct __attribute__((aligned(64))) BvhNode {  // 64 B: both child boxes + child
 struct __attribute__((aligned(128))) Prim {  // 128 B
   // SPHERE / MOVING_SPHERE: f[0..2]=center0, f[3..5]=center1, f[6]=radius
   // QUAD: f[0..2]=Q, f[3..5]=u, f[6..8]=v, f[9..11]=unit normal, f[12]=D, f[13]=1/|u x v|
-  // MEDIUM_SPHERE: f[0..2]=center, f[6]=radius, f[13]=density
-  // MEDIUM_BOX: f[0..2]=corner, f[3..5],f[6..8],f[9..11]=edges, f[13]=density
+  // MEDIUM_SPHERE: f[0..2]=center, f[6]=radius, f[12]=-1/density
+  // MEDIUM_BOX: f[0..2]=corner, f[3..5],f[6..8],f[9..11]=edges, f[12]=-1/density
   double f[14];
   uint32_t type, mat;
   int32_t obj;
@@ -94,7 +94,8 @@ struct Hits {
 #define RT_F_TEX_IMAGE 2u
 #define RT_F_TEX_NOISE 4u
 #define RT_F_QUAD 8u
-#define RT_F_ALL 15u
+#define RT_F_MEDIUM 16u
+#define RT_F_ALL 31u
 
 // ----------------------------------------------------------------------------------------------- RNG
 // Philox4x32-10 (Salmon et al., SC'11).  Counter = (pixel, sample, bounce, purpose), key = seed.
@@ -265,6 +266,54 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
 }
 #pragma clang fp contract(fast)
 
+// EXT constant-density medium with a convex boundary (SURVEY aX3, "The Next Week" §9 in the reference's
+// conventions): boundary entry/exit over (-inf, inf) and (t1 + 1e-4, inf); clamp to the query range; scatter
+// distance -ln(u)/density in units of |d|.  One RNG draw per test.  Sphere boundary or oriented box
+// (corner + three orthogonal edges: an instance-transformed box baked at flatten time).
+__device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, double tmin, double tmax, PathRng& rng,
+                                           double& t_out) {
+  double t1, t2;
+  if (P.type == 3u) {
+    d3 oc = {o.x - P.f[0], o.y - P.f[1], o.z - P.f[2]};
+    double hb = dot(oc, d);
+    double cc = dot(oc, oc) - P.f[6] * P.f[6];
+    double disc = hb * hb - a * cc;
+    if (disc < 0.) return false;
+    double sq = __builtin_sqrt(disc);
+    t1 = (-hb - sq) / a;
+    t2 = (-hb + sq) / a;
+  } else {
+    d3 oq = {o.x - P.f[0], o.y - P.f[1], o.z - P.f[2]};
+    t1 = -__builtin_inf();
+    t2 = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      d3 e = {P.f[3 + 3 * k], P.f[4 + 3 * k], P.f[5 + 3 * k]};
+      double il = 1.0 / dot(e, e);
+      double so = dot(oq, e) * il, sd = dot(d, e) * il;
+      if (__builtin_fabs(sd) < 1e-300) {
+        if (so < 0. || so > 1.) return false;
+      } else {
+        double ta = (0. - so) / sd, tb = (1. - so) / sd;
+        t1 = fmax(t1, fmin(ta, tb));
+        t2 = fmin(t2, fmax(ta, tb));
+      }
+    }
+    if (!(t1 <= t2)) return false;
+  }
+  if (!(t2 > t1 + 0.0001)) return false;  // second boundary hit searched over (t1 + 1e-4, inf)
+  if (t1 < tmin) t1 = tmin;
+  if (t2 > tmax) t2 = tmax;
+  if (t1 >= t2) return false;
+  if (t1 < 0.) t1 = 0.;
+  double len = __builtin_sqrt(a);
+  double dist_inside = (t2 - t1) * len;
+  double hit_distance = P.f[12] * log(u01d(rng_next(rng)));
+  if (hit_distance > dist_inside) return false;
+  t_out = t1 + hit_distance / len;
+  return true;
+}
+
 // Per-ray constants of the f32 slab test.  t = plane*inv - (o*inv); the origin's f32 rounding error
 // |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
 // coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
@@ -369,7 +418,7 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
 // precondition: ts.cur < 0 && ts.cur != RT_DONE
 template <class Acc, class StackT>
 __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_t features, d3 o, d3 d, double time,
-                                          double tmin, StackT* stack, int stride) {
+                                          double tmin, StackT* stack, int stride, PathRng& rng) {
   const int32_t pi = ~ts.cur;
   double t;
   bool h = false;
@@ -383,6 +432,8 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
       h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
     } else if ((features & RT_F_QUAD) && ty == 2u) {
       h = quad_hit(acc.full(pi), o, d, tmin, ts.best_t, t);
+    } else if ((features & RT_F_MEDIUM) && ty >= 3u) {
+      h = medium_hit(acc.full(pi), o, d, ts.a, tmin, ts.best_t, rng, t);
     }
   }
   if (h) {
@@ -400,7 +451,7 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
 // (src/hittable/aabb.rs:48-71) + Sphere/MovingSphere::hit (geometry.rs:36-110).
 template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
-                                            double tmin, StackT* stack, int stride, TravCounters* cnt) {
+                                            double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng) {
   TravState ts;
   trav_init(ts, root, o, d);
   while (ts.cur != RT_DONE) {
@@ -413,7 +464,7 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
     if (ts.cur != RT_DONE) {
       if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
-      leaf_step(acc, ts, features, o, d, time, tmin, stack, stride);
+      leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
     }
   }
@@ -448,6 +499,11 @@ __device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 
     d3 c = sphere_center(g, time);
     h.outward = {(h.p.x - c.x) / g.r, (h.p.y - c.y) / g.r, (h.p.z - c.z) / g.r};
     if (want_uv) { sphere_uv(h.outward, h.u, h.v); h.uv_valid = true; }
+  } else if (acc.type(pi) >= 3u) {  // medium scatter event: arbitrary normal, front face (book convention)
+    h.outward = {1., 0., 0.};
+    h.front = true;
+    h.n = h.outward;
+    return h;
   } else {
     const Prim& P = acc.full(pi);
     h.outward = {P.f[9], P.f[10], P.f[11]};
@@ -641,9 +697,11 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
     PrimGeom g = acc.sphere(hit.prim);
     d3 c = sphere_center(g, time);
     n = __builtin_amdgcn_rcpf((float)g.r) * tof(h.p - c);
-  } else {
+  } else if (acc.type(hit.prim) == 2u) {
     const Prim& P = acc.full(hit.prim);
     n = {(float)P.f[9], (float)P.f[10], (float)P.f[11]};
+  } else {
+    n = -1.0f * normalize(tof(d));  // medium: the isotropic phase function ignores the normal
   }
   h.front = dot(tof(d), n) < 0.f;
   if (!h.front) n = -1.0f * n;

@@ -71,12 +71,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(Scene sc, uint32_t featu
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     d3 o = {q.ox[i], q.oy[i], q.oz[i]}, d = {q.dx[i], q.dy[i], q.dz[i]};
     HitInfo hit;
+    PathRng rng = {0, 0};
+    const bool media = !SPHERES && (features & RT_F_MEDIUM);  // constant media draw from the path's stream inside hit()
+    if (media) { rng.s0 = q.r0[i]; rng.s1 = q.r1[i]; }
     if (SPHERES)
       hit = traverse<SphereAcc, uint32_t, false>(sphere_acc(sc), sc.root, features, o, d, q.time[i], RT_TMIN,
-                                                 stack + threadIdx.x, RT_BLOCK, nullptr);
+                                                 stack + threadIdx.x, RT_BLOCK, nullptr, rng);
     else
       hit = traverse<GlobalAcc, uint32_t, false>(global_acc(sc), sc.root, features, o, d, q.time[i], RT_TMIN,
-                                                 stack + threadIdx.x, RT_BLOCK, nullptr);
+                                                 stack + threadIdx.x, RT_BLOCK, nullptr, rng);
+    if (media) { q.r0[i] = rng.s0; q.r1[i] = rng.s1; }
     h.prim[i] = hit.prim;
     h.t[i] = hit.t;
   }
@@ -283,17 +287,17 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
         my_rays++;
         if (KIND == KIND_SPHERES_LDS) {
           SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE> acc{l_nodes, l_sph, sc.prims};
-          hit = traverse<decltype(acc), StackT, STATS>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, &tc);
+          hit = traverse<decltype(acc), StackT, STATS>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, &tc, rng);
           if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
           so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
           if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
         } else if (KIND == KIND_SPHERES_GLOBAL) {
           SphereAcc acc = sphere_acc(sc);
-          hit = traverse<SphereAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
+          hit = traverse<SphereAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr, rng);
           so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
         } else {
           GlobalAcc acc = global_acc(sc);
-          hit = traverse<GlobalAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr);
+          hit = traverse<GlobalAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr, rng);
           so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
         }
         if (!so.alive) {
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused_sched(Scene sc, Camera cam, Fus
       if (act == 1) {
         if (active && ts.cur < 0 && ts.cur != RT_DONE) {
           if (STATS) { st[2] += 1.f; st[3] += wave_share(); }
-          leaf_step(acc, ts, F, o, d, time, RT_TMIN, stack, BLOCK);
+          leaf_step(acc, ts, F, o, d, time, RT_TMIN, stack, BLOCK, rng);
         }
       } else {
         if (active && ts.cur == RT_DONE) {
@@ -546,8 +550,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
     GlobalAcc acc = global_acc(sc);
+    PathRng rng = {i * 2654435761u + 1u, 0x9E3779B9u};  // only constant media draw (their probe hits are random)
     HitInfo hit = traverse<GlobalAcc, uint32_t, true>(acc, sc.root, features, o, d, r.time, RT_TMIN,
-                                                      stack + threadIdx.x, RT_BLOCK, &tc);
+                                                      stack + threadIdx.x, RT_BLOCK, &tc, rng);
     rt_hit ho;
     memset(&ho, 0, sizeof(ho));
     ho.object_id = -1;
@@ -885,8 +890,40 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       }
       q.f[12] = q.f[9] * Q[0] + q.f[10] * Q[1] + q.f[11] * Q[2];
       q.f[13] = 1.0 / len;
+    } else if (p.type == RT_PRIM_MEDIUM_SPHERE || p.type == RT_PRIM_MEDIUM_BOX) {
+      sc->features |= RT_F_MEDIUM;
+      sc->spheres_only = false;
+      if (!(p.density > 0) || !std::isfinite(p.density))
+        return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": medium density must be > 0");
+      if (d->materials[p.material_id].kind != RT_MAT_ISOTROPIC)
+        return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": a medium needs an ISOTROPIC material");
+      q.f[12] = -1.0 / p.density;
+      if (p.type == RT_PRIM_MEDIUM_SPHERE) {
+        if (!finite3(p.a) || !std::isfinite(p.radius) || p.radius == 0.0)
+          return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": bad medium sphere");
+        for (int a = 0; a < 3; a++) {
+          q.f[a] = p.a[a];
+          b.lo[a] = p.a[a] - std::fabs(p.radius);
+          b.hi[a] = p.a[a] + std::fabs(p.radius);
+        }
+        q.f[6] = p.radius;
+      } else {
+        if (!finite3(p.a) || !finite3(p.b) || !finite3(p.c) || !finite3(p.d))
+          return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": non-finite medium box");
+        const double* e[3] = {p.b, p.c, p.d};
+        for (int k = 0; k < 3; k++)
+          if (!(e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2] > 0))
+            return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": degenerate medium box edge");
+        for (int a = 0; a < 3; a++) {
+          q.f[a] = p.a[a];
+          q.f[3 + a] = p.b[a]; q.f[6 + a] = p.c[a]; q.f[9 + a] = p.d[a];
+          double lo = p.a[a], hi = p.a[a];
+          for (int k = 0; k < 3; k++) { lo += std::fmin(0.0, e[k][a]); hi += std::fmax(0.0, e[k][a]); }
+          b.lo[a] = lo; b.hi[a] = hi;
+        }
+      }
     } else {
-      return fail(ctx, RT_E_UNSUPPORTED, "prim " + std::to_string(i) + ": primitive type not supported yet");
+      return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": unknown primitive type");
     }
   }
   rtb::BuildResult bvh = rtb::build_bvh(boxes, RT_STACK_DEPTH);

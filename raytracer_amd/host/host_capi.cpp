@@ -42,14 +42,18 @@ rth_scene* rth_scene_create(const char* name, uint64_t width, double aspect, int
     else if (n == "book_cover") h->scene = book_cover(cb);
     else if (n == "two_spheres") h->scene = two_spheres(cb);
     else if (n == "something_blocky") h->scene = something_blocky(cb);
-    else if (n == "earth") {
+    else if (n == "cornell_box") h->scene = cornell_box(cb);
+    else if (n == "cornell_smoke") h->scene = cornell_smoke(cb);
+    else if (n == "earth" || n == "final_scene" || n == "final_scene_small") {
       RgbaImage img;
       if (texels) {
         img.width = tw;
         img.height = th;
         img.data.assign(texels, texels + (size_t)4 * tw * th);
       }
-      h->scene = earth(cb, std::move(img));
+      if (n == "earth") h->scene = earth(cb, std::move(img));
+      else if (n == "final_scene") h->scene = final_scene(cb, std::move(img), 20, 1000);
+      else h->scene = final_scene(cb, std::move(img), 6, 60);
     } else {
       throw Error("unknown scene: " + n);
     }

@@ -138,6 +138,22 @@ int32_t Metal::describe(FlatScene& out) const {
     return (int32_t)out.materials.size() - 1;
   });
 }
+int32_t DiffuseLight::describe(FlatScene& out) const {
+  return intern(out.material_ids, this, [&] {
+    rt_material m = blank_material(RT_MAT_DIFFUSE_LIGHT);
+    m.tex = emit_->describe(out);
+    out.materials.push_back(m);
+    return (int32_t)out.materials.size() - 1;
+  });
+}
+int32_t Isotropic::describe(FlatScene& out) const {
+  return intern(out.material_ids, this, [&] {
+    rt_material m = blank_material(RT_MAT_ISOTROPIC);
+    m.tex = albedo_->describe(out);
+    out.materials.push_back(m);
+    return (int32_t)out.materials.size() - 1;
+  });
+}
 int32_t Dielectric::describe(FlatScene& out) const {
   return intern(out.material_ids, this, [&] {
     rt_material m = blank_material(RT_MAT_DIELECTRIC);
@@ -154,17 +170,102 @@ static rt_prim blank_prim(uint32_t type, int32_t object_id, int32_t material) {
   p.material_id = (uint32_t)material;
   return p;
 }
+static void put3(double* dst, const Vec3& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
 void Sphere::describe(FlatScene& out) const {
   rt_prim p = blank_prim(RT_PRIM_SPHERE, (int32_t)out.prims.size(), material->describe(out));
-  p.a[0] = center.x; p.a[1] = center.y; p.a[2] = center.z;
+  put3(p.a, out.xf.point(center));
   p.radius = radius;
+  out.prims.push_back(p);
+}
+void Sphere::describe_boundary(FlatScene& out, double density, int32_t mat) const {
+  rt_prim p = blank_prim(RT_PRIM_MEDIUM_SPHERE, (int32_t)out.prims.size(), mat);
+  put3(p.a, out.xf.point(center));
+  p.radius = radius;
+  p.density = density;
   out.prims.push_back(p);
 }
 void MovingSphere::describe(FlatScene& out) const {
   rt_prim p = blank_prim(RT_PRIM_MOVING_SPHERE, (int32_t)out.prims.size(), sphere.material->describe(out));
-  p.a[0] = sphere.center.x; p.a[1] = sphere.center.y; p.a[2] = sphere.center.z;
-  p.b[0] = destination.x; p.b[1] = destination.y; p.b[2] = destination.z;
+  put3(p.a, out.xf.point(sphere.center));
+  put3(p.b, out.xf.point(destination));
   p.radius = sphere.radius;
+  out.prims.push_back(p);
+}
+void Quad::describe(FlatScene& out) const {
+  rt_prim p = blank_prim(RT_PRIM_QUAD, (int32_t)out.prims.size(), material->describe(out));
+  put3(p.a, out.xf.point(Q));
+  put3(p.b, out.xf.vec(u));
+  put3(p.c, out.xf.vec(v));
+  out.prims.push_back(p);
+}
+namespace {
+struct XformScope {  // push a child transform for the duration of a describe()
+  FlatScene& out;
+  Xform saved;
+  XformScope(FlatScene& o, const Xform& child) : out(o), saved(o.xf) { out.xf = child; }
+  ~XformScope() { out.xf = saved; }
+};
+Xform with_translate(const Xform& m, const Vec3& off) {  // m o translate(off)
+  Xform r = m;
+  Vec3 t = m.vec(off);
+  r.T[0] += t.x; r.T[1] += t.y; r.T[2] += t.z;
+  return r;
+}
+Xform with_rotate_y(const Xform& m, double degrees) {  // m o rotate_y(theta): x' = cos x + sin z, z' = -sin x + cos z
+  const double pi = 3.14159265358979323846264338327950288;
+  const double rad = degrees * (pi / 180.0), c = std::cos(rad), s = std::sin(rad);
+  const double Q[9] = {c, 0, s, 0, 1, 0, -s, 0, c};
+  Xform r = m;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double acc = 0;
+      for (int k = 0; k < 3; k++) acc += m.R[3 * i + k] * Q[3 * k + j];
+      r.R[3 * i + j] = acc;
+    }
+  return r;
+}
+}  // namespace
+void Translate::describe(FlatScene& out) const {
+  XformScope sc(out, with_translate(out.xf, offset_));
+  object_->describe(out);
+}
+void Translate::describe_boundary(FlatScene& out, double density, int32_t mat) const {
+  XformScope sc(out, with_translate(out.xf, offset_));
+  object_->describe_boundary(out, density, mat);
+}
+void RotateY::describe(FlatScene& out) const {
+  XformScope sc(out, with_rotate_y(out.xf, degrees_));
+  object_->describe(out);
+}
+void RotateY::describe_boundary(FlatScene& out, double density, int32_t mat) const {
+  XformScope sc(out, with_rotate_y(out.xf, degrees_));
+  object_->describe_boundary(out, density, mat);
+}
+void ConstantMedium::describe(FlatScene& out) const {
+  boundary_->describe_boundary(out, density_, phase_->describe(out));
+}
+std::unique_ptr<BoxList> box(Point3 a, Point3 b, std::shared_ptr<Material> m) {
+  auto sides = std::make_unique<BoxList>();
+  Point3 mn(std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z));
+  Point3 mx(std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z));
+  sides->min_corner = mn;
+  sides->max_corner = mx;
+  Vec3 dx(mx.x - mn.x, 0, 0), dy(0, mx.y - mn.y, 0), dz(0, 0, mx.z - mn.z);
+  sides->add(std::make_unique<Quad>(Point3(mn.x, mn.y, mx.z), dx, dy, m));    // front
+  sides->add(std::make_unique<Quad>(Point3(mx.x, mn.y, mx.z), -dz, dy, m));   // right
+  sides->add(std::make_unique<Quad>(Point3(mx.x, mn.y, mn.z), -dx, dy, m));   // back
+  sides->add(std::make_unique<Quad>(Point3(mn.x, mn.y, mn.z), dz, dy, m));    // left
+  sides->add(std::make_unique<Quad>(Point3(mn.x, mx.y, mx.z), dx, -dz, m));   // top
+  sides->add(std::make_unique<Quad>(Point3(mn.x, mn.y, mn.z), dx, dz, m));    // bottom
+  return sides;
+}
+void BoxList::describe_boundary(FlatScene& out, double density, int32_t mat) const {
+  rt_prim p = blank_prim(RT_PRIM_MEDIUM_BOX, (int32_t)out.prims.size(), mat);
+  put3(p.a, out.xf.point(min_corner));
+  put3(p.b, out.xf.vec(Vec3(max_corner.x - min_corner.x, 0, 0)));
+  put3(p.c, out.xf.vec(Vec3(0, max_corner.y - min_corner.y, 0)));
+  put3(p.d, out.xf.vec(Vec3(0, 0, max_corner.z - min_corner.z)));
+  p.density = density;
   out.prims.push_back(p);
 }
 void HittableList::describe(FlatScene& out) const {
@@ -228,6 +329,10 @@ Camera CameraBuilder::build() const {  // builder.rs:55-134
   const double defocus_radius = c.focus_distance * std::tan((c.defocus_angle / 2.0) * (pi / 180.0));
   c.defocus_disk_u = defocus_radius * c.u;
   c.defocus_disk_v = defocus_radius * c.v;
+  if (background_) {
+    c.solid_background = true;
+    c.background = *background_;
+  }
   return c;
 }
 
@@ -243,7 +348,8 @@ rt_camera Camera::abi_camera() const {
   c.sampler_kind = pixel_sampler.kind == PixelSamplerKind::Uniform ? RT_SAMPLER_UNIFORM : RT_SAMPLER_RANDOM;
   c.sampler_n = (uint32_t)pixel_sampler.n;
   c.max_depth = (uint32_t)depth;
-  c.background_mode = 0;
+  c.background_mode = solid_background ? 1 : 0;
+  c.background[0] = background.r; c.background[1] = background.g; c.background[2] = background.b;
   auto put = [](double* dst, const Vec3& v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
   put(c.center, center);
   put(c.pixel00, pixel00_loc);
@@ -428,6 +534,94 @@ Scene something_blocky(CameraBuilder camera_builder) {  // scene.rs:262-285
   auto material = std::make_shared<Lambertian>(noise_texture);
   world->add(std::make_unique<Sphere>(Point3(0.0, -1000.0, 0.0), 1000.0, material));
   world->add(std::make_unique<Sphere>(Point3(0.0, 2.0, 0.0), 2.0, material));
+  sc.world = world->into_bvh();
+  return sc;
+}
+
+// ------------------------------------------------------------------ EXT scenes (book scenes; not in the reference)
+static void cornell_walls(HittableList& world) {
+  auto red = std::make_shared<Lambertian>(Color(.65, .05, .05));
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  auto green = std::make_shared<Lambertian>(Color(.12, .45, .15));
+  auto light = std::make_shared<DiffuseLight>(Color(7, 7, 7));
+  world.add(std::make_unique<Quad>(Point3(555, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), green));
+  world.add(std::make_unique<Quad>(Point3(0, 0, 0), Vec3(0, 555, 0), Vec3(0, 0, 555), red));
+  world.add(std::make_unique<Quad>(Point3(113, 554, 127), Vec3(330, 0, 0), Vec3(0, 0, 305), light));
+  world.add(std::make_unique<Quad>(Point3(0, 555, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+  world.add(std::make_unique<Quad>(Point3(0, 0, 0), Vec3(555, 0, 0), Vec3(0, 0, 555), white));
+  world.add(std::make_unique<Quad>(Point3(0, 0, 555), Vec3(555, 0, 0), Vec3(0, 555, 0), white));
+}
+static CameraBuilder cornell_camera(CameraBuilder cb) {
+  return cb.background(Color(0, 0, 0)).field_of_view(40.0).lookfrom(Point3(278, 278, -800)).lookat(Point3(278, 278, 0))
+      .up_vector(Vec3(0, 1, 0)).defocus_angle(0.0);
+}
+Scene cornell_box(CameraBuilder camera_builder) {
+  Scene sc;
+  sc.camera = cornell_camera(camera_builder).build();
+  auto world = std::make_unique<HittableList>();
+  cornell_walls(*world);
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  world->add(std::make_unique<Translate>(
+      std::make_unique<RotateY>(box(Point3(0, 0, 0), Point3(165, 330, 165), white), 15.0), Vec3(265, 0, 295)));
+  world->add(std::make_unique<Translate>(
+      std::make_unique<RotateY>(box(Point3(0, 0, 0), Point3(165, 165, 165), white), -18.0), Vec3(130, 0, 65)));
+  sc.world = world->into_bvh();
+  return sc;
+}
+Scene cornell_smoke(CameraBuilder camera_builder) {
+  Scene sc;
+  sc.camera = cornell_camera(camera_builder).build();
+  auto world = std::make_unique<HittableList>();
+  cornell_walls(*world);
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  world->add(std::make_unique<ConstantMedium>(
+      std::make_unique<Translate>(std::make_unique<RotateY>(box(Point3(0, 0, 0), Point3(165, 330, 165), white), 15.0),
+                                  Vec3(265, 0, 295)),
+      0.01, Color(0, 0, 0)));
+  world->add(std::make_unique<ConstantMedium>(
+      std::make_unique<Translate>(std::make_unique<RotateY>(box(Point3(0, 0, 0), Point3(165, 165, 165), white), -18.0),
+                                  Vec3(130, 0, 65)),
+      0.01, Color(1, 1, 1)));
+  sc.world = world->into_bvh();
+  return sc;
+}
+Scene final_scene(CameraBuilder camera_builder, RgbaImage earth_image, int boxes_per_side, int cluster_spheres) {
+  Scene sc;
+  sc.camera = camera_builder.background(Color(0, 0, 0)).field_of_view(40.0).lookfrom(Point3(478, 278, -600))
+                  .lookat(Point3(278, 278, 0)).up_vector(Vec3(0, 1, 0)).defocus_angle(0.0).build();
+  Rng rng = Rng::from_seed(2024, 7);  // the reference's generator, fixed seed (host and oracle agree)
+  auto world = std::make_unique<HittableList>();
+  auto ground = std::make_shared<Lambertian>(Color(0.48, 0.83, 0.53));
+  const double w = 2000.0 / (double)boxes_per_side;
+  for (int i = 0; i < boxes_per_side; i++)
+    for (int j = 0; j < boxes_per_side; j++) {
+      const double x0 = -1000.0 + i * w, z0 = -1000.0 + j * w, y0 = 0.0;
+      const double x1 = x0 + w, y1 = rng.next_f64_range(1.0, 101.0), z1 = z0 + w;
+      world->add(box(Point3(x0, y0, z0), Point3(x1, y1, z1), ground));
+    }
+  world->add(std::make_unique<Quad>(Point3(123, 554, 147), Vec3(300, 0, 0), Vec3(0, 0, 265),
+                                    std::make_shared<DiffuseLight>(Color(7, 7, 7))));
+  const Point3 center1(400, 400, 200);
+  world->add(std::make_unique<MovingSphere>(Sphere(center1, 50, std::make_shared<Lambertian>(Color(0.7, 0.3, 0.1))),
+                                            center1 + Vec3(30, 0, 0)));
+  world->add(std::make_unique<Sphere>(Point3(260, 150, 45), 50, std::make_shared<Dielectric>(1.5)));
+  world->add(std::make_unique<Sphere>(Point3(0, 150, 145), 50, std::make_shared<Metal>(Color(0.8, 0.8, 0.9), 1.0)));
+  world->add(std::make_unique<Sphere>(Point3(360, 150, 145), 70, std::make_shared<Dielectric>(1.5)));
+  world->add(std::make_unique<ConstantMedium>(
+      std::make_unique<Sphere>(Point3(360, 150, 145), 70, std::make_shared<Dielectric>(1.5)), 0.2, Color(0.2, 0.4, 0.9)));
+  world->add(std::make_unique<ConstantMedium>(
+      std::make_unique<Sphere>(Point3(0, 0, 0), 5000, std::make_shared<Dielectric>(1.5)), .0001, Color(1, 1, 1)));
+  world->add(std::make_unique<Sphere>(Point3(400, 200, 400), 100,
+                                      std::make_shared<Lambertian>(std::make_shared<ImageTexture>(std::move(earth_image)))));
+  world->add(std::make_unique<Sphere>(Point3(220, 280, 300), 80,
+                                      std::make_shared<Lambertian>(std::make_shared<NoiseTexture>(0.2))));
+  auto white = std::make_shared<Lambertian>(Color(.73, .73, .73));
+  auto cluster = std::make_unique<HittableList>();
+  for (int j = 0; j < cluster_spheres; j++) {
+    const double x = rng.next_f64_range(0.0, 165.0), y = rng.next_f64_range(0.0, 165.0), z = rng.next_f64_range(0.0, 165.0);
+    cluster->add(std::make_unique<Sphere>(Point3(x, y, z), 10, white));
+  }
+  world->add(std::make_unique<Translate>(std::make_unique<RotateY>(cluster->into_bvh(), 15.0), Vec3(-100, 270, 395)));
   sc.world = world->into_bvh();
   return sc;
 }

@@ -88,7 +88,20 @@ inline Color operator/(Color a, double s) { return {a.r / s, a.g / s, a.b / s}; 
 inline Color operator+(Color a, double s) { return {a.r + s, a.g + s, a.b + s}; }
 
 // ------------------------------------------------------------------ flattening target
+struct Xform {  // p_world = R p + T (row-major R); instances are baked into the primitives while flattening
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double T[3] = {0, 0, 0};
+  Vec3 point(const Vec3& p) const {
+    return {R[0] * p.x + R[1] * p.y + R[2] * p.z + T[0], R[3] * p.x + R[4] * p.y + R[5] * p.z + T[1],
+            R[6] * p.x + R[7] * p.y + R[8] * p.z + T[2]};
+  }
+  Vec3 vec(const Vec3& v) const {
+    return {R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z,
+            R[6] * v.x + R[7] * v.y + R[8] * v.z};
+  }
+};
 struct FlatScene {
+  Xform xf;  // current instance transform (identity at top level)
   std::vector<rt_prim> prims;
   std::vector<rt_material> materials;
   std::vector<rt_texture> textures;
@@ -165,6 +178,23 @@ class Metal : public Material {  // materials.rs:59-86
   Color albedo_;
   double fuzz_;
 };
+class DiffuseLight : public Material {  // EXT (SURVEY aX4): emits, never scatters
+ public:
+  explicit DiffuseLight(Color emit) : emit_(std::make_shared<SolidColor>(emit)) {}
+  explicit DiffuseLight(std::shared_ptr<Texture> emit) : emit_(std::move(emit)) {}
+  int32_t describe(FlatScene& out) const override;
+
+ private:
+  std::shared_ptr<Texture> emit_;
+};
+class Isotropic : public Material {  // EXT (SURVEY aX3): phase function of a constant medium
+ public:
+  explicit Isotropic(Color albedo) : albedo_(std::make_shared<SolidColor>(albedo)) {}
+  int32_t describe(FlatScene& out) const override;
+
+ private:
+  std::shared_ptr<Texture> albedo_;
+};
 class Dielectric : public Material {  // materials.rs:89-102
  public:
   explicit Dielectric(double index_of_refraction) : ior_(index_of_refraction) {}
@@ -179,15 +209,60 @@ class Hittable {  // hittable/mod.rs:26-29 + describe()
  public:
   virtual ~Hittable() = default;
   virtual void describe(FlatScene& out) const = 0;
+  // EXT: describe this object as the convex boundary of a constant medium (sphere or box, possibly instanced)
+  virtual void describe_boundary(FlatScene&, double /*density*/, int32_t /*material*/) const {
+    throw Error("ConstantMedium: boundary must be a Sphere or a box (optionally under Translate / RotateY)");
+  }
 };
 class Sphere : public Hittable {  // geometry.rs:12-28
  public:
   Sphere(Point3 center, double radius, std::shared_ptr<Material> material)
       : center(center), radius(radius), material(std::move(material)) {}
   void describe(FlatScene& out) const override;
+  void describe_boundary(FlatScene& out, double density, int32_t material) const override;
   Point3 center;
   double radius;
   std::shared_ptr<Material> material;
+};
+// ---- EXT geometry (absent from the reference; "The Next Week" definitions in the reference's conventions)
+class Quad : public Hittable {  // SURVEY aX1
+ public:
+  Quad(Point3 Q, Vec3 u, Vec3 v, std::shared_ptr<Material> material) : Q(Q), u(u), v(v), material(std::move(material)) {}
+  void describe(FlatScene& out) const override;
+  Point3 Q;
+  Vec3 u, v;
+  std::shared_ptr<Material> material;
+};
+class Translate : public Hittable {  // SURVEY aX2
+ public:
+  Translate(std::unique_ptr<Hittable> object, Vec3 offset) : object_(std::move(object)), offset_(offset) {}
+  void describe(FlatScene& out) const override;
+  void describe_boundary(FlatScene& out, double density, int32_t material) const override;
+
+ private:
+  std::unique_ptr<Hittable> object_;
+  Vec3 offset_;
+};
+class RotateY : public Hittable {  // SURVEY aX2
+ public:
+  RotateY(std::unique_ptr<Hittable> object, double degrees) : object_(std::move(object)), degrees_(degrees) {}
+  void describe(FlatScene& out) const override;
+  void describe_boundary(FlatScene& out, double density, int32_t material) const override;
+
+ private:
+  std::unique_ptr<Hittable> object_;
+  double degrees_;
+};
+class ConstantMedium : public Hittable {  // SURVEY aX3
+ public:
+  ConstantMedium(std::unique_ptr<Hittable> boundary, double density, Color albedo)
+      : boundary_(std::move(boundary)), density_(density), phase_(std::make_shared<Isotropic>(albedo)) {}
+  void describe(FlatScene& out) const override;
+
+ private:
+  std::unique_ptr<Hittable> boundary_;
+  double density_;
+  std::shared_ptr<Material> phase_;
 };
 class MovingSphere : public Hittable {  // geometry.rs:84-100
  public:
@@ -204,6 +279,13 @@ class HittableList : public Hittable {  // containers.rs:13-26
   std::unique_ptr<Hittable> into_bvh();
   void describe(FlatScene& out) const override;
   std::vector<std::unique_ptr<Hittable>> objects;
+};
+class BoxList;
+std::unique_ptr<BoxList> box(Point3 a, Point3 b, std::shared_ptr<Material> material);  // EXT: six quads
+class BoxList : public HittableList {
+ public:
+  void describe_boundary(FlatScene& out, double density, int32_t material) const override;
+  Point3 min_corner, max_corner;
 };
 class BVHNode : public Hittable {  // containers.rs:48-52 (opaque on the host; see into_bvh)
  public:
@@ -254,6 +336,7 @@ class CameraBuilder {  // builder.rs:8-54
   CameraBuilder& focus_distance(double v) { focus_distance_ = v; return *this; }
   CameraBuilder& uniform_sampler(size_t spp) { sampler_ = PixelSampler{PixelSamplerKind::Uniform, spp}; return *this; }
   CameraBuilder& random_sampler(size_t spp) { sampler_ = PixelSampler{PixelSamplerKind::Random, spp}; return *this; }
+  CameraBuilder& background(Color c) { background_ = c; return *this; }  // EXT (aX4): solid background instead of the sky
   Camera build() const;  // builder.rs:55-134; throws Error where the reference panics
 
  private:
@@ -263,6 +346,7 @@ class CameraBuilder {  // builder.rs:8-54
   std::optional<double> field_of_view_, defocus_angle_, focus_distance_;
   std::optional<Point3> lookfrom_, lookat_;
   std::optional<Vec3> up_vector_;
+  std::optional<Color> background_;
 };
 
 // Binding of a Camera to a GPU context: which ctx renders, the RNG seed, where the `image.ppm` goes
@@ -288,6 +372,8 @@ class Camera {  // mod.rs:26-51
   size_t samples_per_pixel() const;
   PixelSampler pixel_sampler{PixelSamplerKind::Uniform, 1};
   size_t depth = 0;
+  bool solid_background = false;  // EXT: false = the reference's sky gradient (mod.rs:205-207)
+  Color background;
   double aspect_ratio = 1, field_of_view = 90, defocus_angle = 0, focus_distance = 1;
   Point3 lookfrom, lookat, center, pixel00_loc;
   Vec3 up_vector, pixel_delta_u, pixel_delta_v, u, v, w, defocus_disk_u, defocus_disk_v;
@@ -306,5 +392,9 @@ Scene book_cover(CameraBuilder camera_builder);        // scene.rs:89-164
 Scene two_spheres(CameraBuilder camera_builder);       // scene.rs:216-241
 Scene earth(CameraBuilder camera_builder, RgbaImage earth_image);  // scene.rs:243-260 (image decoded by the caller)
 Scene something_blocky(CameraBuilder camera_builder);  // scene.rs:262-285
+// EXT scenes (not in the reference; book scenes built with the reference's types + the EXT types above)
+Scene cornell_box(CameraBuilder camera_builder);                       // quads + two rotated boxes + light
+Scene cornell_smoke(CameraBuilder camera_builder);                     // the boxes as constant media
+Scene final_scene(CameraBuilder camera_builder, RgbaImage earth_image, int boxes_per_side, int cluster_spheres);
 
 }  // namespace raytracer
