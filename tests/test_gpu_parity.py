@@ -130,6 +130,8 @@ def image_parity(ctx, name, width, sampler, spp, depth, seed=1234):
     ("book_cover", "random", 4096, 50),    # C1's sampler
     ("composition", "uniform", 4096, 16),  # plain list, r=4e7 ground, negative-radius hollow glass, mirror
     ("two_spheres", "uniform", 2500, 50),
+    ("earth", "uniform", 1024, 50),             # C3a: image texture (u,v from acos/atan2, nearest texel)
+    ("something_blocky", "uniform", 1024, 50),  # C3b: Hermite lattice noise (xoroshiro jump hash)
 ])
 def test_converged_image_parity(ctx, name, sampler, spp, depth):
     r = image_parity(ctx, name, 64, sampler, spp, depth)

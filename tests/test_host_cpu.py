@@ -152,3 +152,32 @@ def test_oracle_is_not_linked_into_the_product():
                 src = open(os.path.join(root, f)).read()
                 assert "oracle_lib" not in src and "liboracle" not in src and "oracle/" not in src.replace(
                     "under oracle/", ""), f
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "cornell_smoke", "final_scene_small"])
+def test_ext_scenes_host_matches_oracle_structure(name):
+    """EXT scenes (SURVEY aX1-aX5): same object count / camera on both sides; instances are baked on the host."""
+    from golden_data import load_earth_rgba
+    tex = load_earth_rgba() if name.startswith("final") else None
+    o = OracleScene(name, 100, 1.0, "uniform", 4, 20, texels=tex)
+    g = ra.Scene(name, 100, 1.0, "uniform", 4, 20, texels=tex)
+    assert g.desc.n_prims == o.n_objects
+    p = g.prims()
+    assert (p["object_id"] == np.arange(len(p))).all()
+    assert g.camera.background_mode == 1 and tuple(g.camera.background) == (0.0, 0.0, 0.0)
+    assert (g.width, g.height) == (100, 100)
+    if name == "cornell_box":
+        assert (p["type"] == 2).all() and len(p) == 18
+        # box1: 165x330x165 rotated 15 deg about Y then translated (265,0,295): its bottom face keeps y = 0 and
+        # every edge keeps its length
+        quads = p[6:12]
+        assert np.allclose(np.linalg.norm(quads["b"], axis=1), [165, 165, 165, 165, 165, 165])
+        assert np.allclose(sorted(np.linalg.norm(quads["c"], axis=1)), [165, 165, 330, 330, 330, 330])
+        assert np.isclose(quads["a"][:, 1].min(), 0.0) and np.isclose(quads["a"][:, 1].max(), 330.0)
+        c, s_ = np.cos(np.radians(15)), np.sin(np.radians(15))
+        # front face Q = (0,0,165) -> (cos*0 + sin*165 + 265, 0, -sin*0 + cos*165 + 295)
+        assert np.allclose(quads["a"][0], [s_ * 165 + 265, 0, c * 165 + 295])
+    if name == "cornell_smoke":
+        assert list(p["type"]) == [2] * 6 + [4, 4] and list(p["density"][6:]) == [0.01, 0.01]
+    if name == "final_scene_small":
+        assert (p["type"] == 3).sum() == 2 and (p["type"] == 1).sum() == 1
