@@ -33,26 +33,31 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
 
 WORKLOADS = {
-    # name: (scene, width, sampler, spp, depth, workload fixture)
+    # name: (scene, width, sampler, spp rendered per step, depth, workload fixture)
     "c1": ("book_cover", 400, "random", 10, 50, "workload_c1.json"),
     "c2": ("book_cover", 1200, "uniform", 100, 50, "workload_c2.json"),
+    "c3a": ("earth", 1920, "uniform", 256, 50, "workload_c3a.json"),
+    "c3b": ("something_blocky", 1920, "uniform", 256, 50, "workload_c3b.json"),
+    "c4": ("cornell_smoke", 1920, "uniform", 64, 50, "workload_c4.json"),    # config: 1024 spp; step = 64 spp slice
+    "c5": ("final_scene", 3840, "uniform", 16, 50, "workload_c5.json"),      # config: 10 000 spp; step = 16 spp slice
 }
 
 
-def cpu_baseline(scene, width, depth):
+def cpu_baseline(scene, width, depth, texels=None):
     """Oracle (kind 'port') on a bounded sample of the same workload: same frame, uniform 3x3 = 9 spp."""
     from oracle_lib import OracleScene
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share is 16
-    sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", 9, depth)
+    sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", 9 if width <= 1920 else 1, depth, texels=texels)
     r = sc.render(threads=threads)
-    n = sc.width * sc.height * 9
+    cspp = 9 if width <= 1920 else 1
+    n = sc.width * sc.height * cspp
     # 1-thread figure on a sub-window (the reference's Arc refcount contention makes it scale sub-linearly)
     win = (0, sc.height // 2 // 32 * 32, sc.width, 64)
     r1 = sc.render(threads=1, window=win)
-    n1 = min(64, sc.height - win[1]) * sc.width * 9
+    n1 = min(64, sc.height - win[1]) * sc.width * cspp
     return {
         "value": n / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": f"{scene} {sc.width}x{sc.height}, uniform 9 spp (3x3 grid), depth {depth}: {n} samples, "
+        "sample": f"{scene} {sc.width}x{sc.height}, uniform {cspp} spp, depth {depth}: {n} samples, "
                   f"{r['seconds']:.2f} s",
         "one_thread_value": n1 / r1["seconds"] / 1e6,
         "one_thread_sample": f"rows {win[1]}..{win[1] + 64}, {n1} samples, {r1['seconds']:.2f} s",
@@ -91,7 +96,11 @@ def main():
     # weak scaling: every rank renders `spp` samples per pixel; the frame holds world*spp samples.
     # Uniform sampler needs a square count: use the grid of the config per rank by offsetting the seed per rank
     # (decorrelated Philox streams per GPU) and letting each rank render the config's full grid.
-    host_scene = ra.Scene(scene_name, width, 16.0 / 9.0, sampler, spp, depth)
+    texels = None
+    if scene_name in ("earth", "final_scene"):
+        from golden_data import load_earth_rgba
+        texels = load_earth_rgba()
+    host_scene = ra.Scene(scene_name, width, 16.0 / 9.0, sampler, spp, depth, texels=texels)
     dev_scene = host_scene.upload(ctx)
     cam = host_scene.camera_copy()
     W, H = host_scene.width, host_scene.height
@@ -159,9 +168,9 @@ def main():
             "metric": "Msamples/sec (pixels x spp)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + f32 culling/shading",
-            "data": "synthetic (reference scene builder book_cover, seed [42,1337])",
+            "data": f"synthetic (scene builder {scene_name}, fixed seeds)",
             "config": {"workload": f"{args.workload}: {scene_name} {W}x{H}, {sampler}_sampler({host_scene.spp}), "
-                                   f"depth {depth}, 484 spheres (480 moving), defocus 0.3deg",
+                                   f"depth {depth}, {host_scene.desc.n_prims} primitives",
                        "spp_per_gpu": host_scene.spp, "samples_per_step": samples_per_rank * world,
                        "parallelism": f"sample-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -173,7 +182,7 @@ def main():
         if stage:
             out["roofline"]["stage_ms"] = stage
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_name, width, depth)
+            out["cpu_baseline"] = cpu_baseline(scene_name, width, depth, texels)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -21,6 +21,8 @@ CONFIGS = {
     "c2": ("book_cover", 1200, "uniform", 100, 50, 9),
     "c3a": ("earth", 1920, "uniform", 256, 50, 4),
     "c3b": ("something_blocky", 1920, "uniform", 256, 50, 4),
+    "c4": ("cornell_smoke", 1920, "uniform", 1024, 50, 4),
+    "c5": ("final_scene", 3840, "uniform", 10000, 50, 1),
 }
 
 
@@ -41,7 +43,7 @@ def main():
     if len(sys.argv) > 2:
         cspp = int(sys.argv[2])
     tex = None
-    if scene == "earth":
+    if scene in ("earth", "final_scene"):
         from golden_data import load_earth_rgba
         tex = load_earth_rgba()
     sc = OracleScene(scene, width, 16.0 / 9.0, sampler, cspp, depth, texels=tex, counting=True)
