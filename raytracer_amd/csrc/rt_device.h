@@ -444,6 +444,33 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
   trav_pop(ts, stack, stride);
 }
 
+// Advance the traversals of the participating lanes in while-while form until fewer than `min_lanes` of them are
+// still walking (wave-uniform exit).  min_lanes = 1 runs every traversal to completion; a larger value hands the
+// wave back early so that finished lanes can be shaded / re-launched while the stragglers keep their state.
+template <class Acc, class StackT, bool COUNT>
+__device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, bool participating, uint32_t features,
+                                                d3 o, d3 d, double time, double tmin, StackT* stack, int stride,
+                                                TravCounters* cnt, PathRng& rng, uint32_t min_lanes) {
+  while (true) {
+    const bool busy = participating && ts.cur != RT_DONE;
+    if ((uint32_t)__popcll(__ballot(busy)) < min_lanes) break;
+    if (busy) {
+      uint64_t t0 = 0;
+      if (COUNT) t0 = now_cycles();
+      while (ts.cur >= 0) {
+        if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
+        node_step(acc, ts, stack, stride);
+      }
+      if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
+      if (ts.cur != RT_DONE) {
+        if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
+        leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
+        if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
+      }
+    }
+  }
+}
+
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
 // stack (entries `stride` elements apart => bank-conflict free).  "while-while" form: lanes walk inner
 // nodes until they hold a leaf, then the wave runs the (expensive, f64) leaf test together.

@@ -205,6 +205,20 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
   return (unsigned long long)(v * RT_FIX_SCALE);
 }
 
+template <int KIND> struct AccOf;
+template <> struct AccOf<KIND_SPHERES_LDS> {
+  using type = SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE>;
+  static __device__ __forceinline__ type make(const Scene& sc, const float4* ln, const SphereRec* ls) { return type{ln, ls, sc.prims}; }
+};
+template <> struct AccOf<KIND_SPHERES_GLOBAL> {
+  using type = SphereAcc;
+  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return sphere_acc(sc); }
+};
+template <> struct AccOf<KIND_GENERIC> {
+  using type = GlobalAcc;
+  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return global_acc(sc); }
+};
+
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
 __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
   off += (size_t)(BLOCK / 64) * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
   if (KIND == KIND_SPHERES_LDS) __syncthreads();
+  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph);
 
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long my_rays = 0;
@@ -252,10 +267,14 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
     d3 o = {0, 0, 0}, d = {0, 0, 0};
     double time = 0;
     f3 thr = {1.f, 1.f, 1.f};
-    uint32_t pixel = 0, s = 0, depth = 0, lpix = 0;
+    uint32_t depth = 0, lpix = 0;
     PathRng rng = {0, 0};
+    TravState ts;
+    ts.cur = RT_DONE; ts.sp = 0; ts.top = RT_DONE; ts.best_prim = -1; ts.tmax32 = 0.f; ts.best_t = 0; ts.a = 1; ts.inv_a = 1;
+    ts.s = SlabRay{0, 0, 0, 0, 0, 0, 0, 0, 0, false, false, false};
+    bool fresh = false;  // wave-uniform: some lane received a new ray since the last traversal call
     while (true) {
-      // ---- regenerate: lanes without a path take the next samples of the pool
+      // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
       unsigned long long need = __ballot(!active);
       if (STATS) st_t0 = now_cycles();
       if (need && next < total) {
@@ -265,50 +284,53 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
           uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
           if (px < cam.width && py < cam.height) {
             if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
-            pixel = py * cam.width + px;
-            s = fp.s_begin + (k_lo + ks) * fp.s_stride;
+            uint32_t pixel = py * cam.width + px;
+            uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
             generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
             thr = {1.f, 1.f, 1.f};
             depth = 0;
             lpix = pit;
             active = true;
+            trav_init(ts, sc.root, o, d);
+            my_rays++;
           }
         }
         next = min(total, next + (uint32_t)__popcll(need));
+        fresh = true;
       }
       if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
       if (__ballot(active) == 0ull) {
         if (next >= total) break;
         continue;
       }
-      if (active) {
+      // ---- traverse: hand the wave back once fewer than kn lanes are still walking (stragglers keep their
+      //      TravState and continue next round next to the re-launched lanes); with nothing new to launch, finish
+      traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
+                                                                 &tc, rng, fresh ? fp.kn : 1u);
+      // ---- shade the lanes whose traversal is complete
+      const bool ready = active && ts.cur == RT_DONE;
+      fresh = __ballot(ready) != 0ull;
+      if (ready) {
         HitInfo hit;
-        ShadeOut so;
-        my_rays++;
-        if (KIND == KIND_SPHERES_LDS) {
-          SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE> acc{l_nodes, l_sph, sc.prims};
-          hit = traverse<decltype(acc), StackT, STATS>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, &tc, rng);
-          if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
-          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
-          if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
-        } else if (KIND == KIND_SPHERES_GLOBAL) {
-          SphereAcc acc = sphere_acc(sc);
-          hit = traverse<SphereAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr, rng);
-          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
-        } else {
-          GlobalAcc acc = global_acc(sc);
-          hit = traverse<GlobalAcc, StackT, false>(acc, sc.root, F, o, d, time, RT_TMIN, stack, BLOCK, nullptr, rng);
-          so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
-        }
+        hit.t = ts.best_t;
+        hit.prim = ts.best_prim;
+        if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
+        ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
+        if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
         if (!so.alive) {
           atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
           atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
           atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
           active = false;
         } else {
-          o = so.o; d = so.d; thr = so.thr;
           depth++;
-          if (depth >= cam.max_depth) active = false;  // mod.rs:195-197: black
+          if (depth >= cam.max_depth) {
+            active = false;  // mod.rs:195-197: black
+          } else {
+            o = so.o; d = so.d; thr = so.thr;
+            trav_init(ts, sc.root, o, d);
+            my_rays++;
+          }
         }
       }
     }
@@ -347,20 +369,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
 // shade + regenerate (S).  A lane whose traversal ends early is reshaded and re-launched while its neighbours
 // keep walking the tree, which is what lifts the SIMD lane utilisation of the node loop (profiles/: 32 % in
 // k_fused).  Thresholds kn / kl / ks are runtime parameters (FusedParams).
-template <int KIND> struct AccOf;
-template <> struct AccOf<KIND_SPHERES_LDS> {
-  using type = SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE>;
-  static __device__ __forceinline__ type make(const Scene& sc, const float4* ln, const SphereRec* ls) { return type{ln, ls, sc.prims}; }
-};
-template <> struct AccOf<KIND_SPHERES_GLOBAL> {
-  using type = SphereAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return sphere_acc(sc); }
-};
-template <> struct AccOf<KIND_GENERIC> {
-  using type = GlobalAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return global_acc(sc); }
-};
-
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
 __global__ __launch_bounds__(BLOCK) void k_fused_sched(Scene sc, Camera cam, FusedParams fp,
                                                        uint32_t* __restrict__ unit_counter,
@@ -608,7 +616,7 @@ struct rt_ctx {
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
   int fused_block = 1024;    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
   int fused_sched = 0;       // 1 = k_fused_sched (phase scheduler), 0 = k_fused (bounce-synchronous)
-  int sched_kn = 24, sched_kl = 8, sched_ks = 24;
+  int sched_kn = 1, sched_kl = 8, sched_ks = 24;  // kn also = early hand-back threshold of k_fused (1 = off)
   float* d_dbg = nullptr;
   WorkBuffers wb;
   uint32_t* d_unit_counter = nullptr;

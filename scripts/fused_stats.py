@@ -47,3 +47,9 @@ if "--sweep" in sys.argv:
         for kl in (8, 16, 24, 32):
             for ks in (24, 32, 40, 48, 56):
                 run(False, fused_sched=1, sched_kn=kn, sched_kl=kl, sched_ks=ks)
+if "--handback" in sys.argv:  # k_fused early hand-back threshold (sched_kn doubles as it; 1 = run to completion)
+    for kn in (1, 8, 16, 24, 32, 40, 48):
+        run(False, fused_sched=0, sched_kn=kn)
+    run(True, fused_sched=0, sched_kn=1)
+    run(True, fused_sched=0, sched_kn=24)
+    run(True, fused_sched=0, sched_kn=40)

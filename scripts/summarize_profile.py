@@ -1,0 +1,33 @@
+"""Summarise a gpurun_out/<tag>/ profile directory (scripts/gpu_profile.sh) into profiles/<tag>_*.{csv,json}."""
+import collections, csv, json, os, shutil, sys
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
+out = {"command": "rocprofv3 --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline (one pass per group)",
+       "kernel": None, "counters": {}}
+for d in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write", "pmc_l2"):
+    p = os.path.join(src, d, "p_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    for r in csv.DictReader(open(p)):
+        if "k_fused" in r["Kernel_Name"] or "k_intersect" in r["Kernel_Name"] or "k_shade" in r["Kernel_Name"]:
+            out["kernel"] = out["kernel"] or r["Kernel_Name"].split("(")[0]
+            out["counters"][r["Counter_Name"]] = out["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+c = out["counters"]
+der = {}
+if "SQ_INSTS_VALU" in c:
+    der["valu_active_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64)
+if "FETCH_SIZE" in c:
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) under-reports wide coalesced reads by 2x on gfx950; this kernel's
+    # reads are scattered 4-64 B texture/material fetches, so the raw value is reported with that caveat
+    der["hbm_fetch_bytes_raw"] = c["FETCH_SIZE"] * 1024
+    der["hbm_fetch_bytes_x2_upper"] = c["FETCH_SIZE"] * 2048
+if "WRITE_SIZE" in c:
+    der["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+if "TCC_HIT_sum" in c:
+    der["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
+out["derived"] = der
+json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+print(json.dumps(der, indent=1))
+print(open(f"profiles/{tag}_kernel_stats.csv").read()[:700])
