@@ -151,6 +151,60 @@ __device__ __forceinline__ f3 normalize(f3 a) {
   return inv * a;
 }
 
+// ----------------------------------------------------------------------------------------------- slab test
+// Per-ray constants of the f32 slab test.  t = plane*inv - (o*inv); the origin's f32 rounding error
+// |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
+// coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
+struct SlabRay {
+  float ix, iy, iz;
+  float nx, ny, nz;
+  float fx, fy, fz;
+  bool sx, sy, sz;       // direction negative on axis (select-based node fetch: GlobalAcc / SphereAcc)
+  uint32_t ox, oy, oz;   // byte offset of the ray's direction-ordered plane quad inside a slab node (SlabLdsAcc)
+};
+#define RT_SLAB_NODE_BYTES 112  // see SlabLdsAcc
+#define RT_SLAB_REGION_BYTES(n_nodes) ((size_t)(n_nodes) * RT_SLAB_NODE_BYTES)
+__device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
+  SlabRay s;
+  float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+  s.ix = __builtin_amdgcn_rcpf((float)d.x);
+  s.iy = __builtin_amdgcn_rcpf((float)d.y);
+  s.iz = __builtin_amdgcn_rcpf((float)d.z);
+  float ax = ox * s.ix, ay = oy * s.iy, az = oz * s.iz;
+  const float E = 9.5367431640625e-07f;  // 2^-20: > 8 ulp, covers o / d / rcp / fma rounding
+  float ex = __builtin_fabsf(ax) * E, ey = __builtin_fabsf(ay) * E, ez = __builtin_fabsf(az) * E;
+  s.nx = ax + ex; s.ny = ay + ey; s.nz = az + ez;
+  s.fx = ax - ex; s.fy = ay - ey; s.fz = az - ez;
+  s.sx = s.ix < 0.f; s.sy = s.iy < 0.f; s.sz = s.iz < 0.f;
+  s.ox = s.sx ? 16u : 0u; s.oy = s.sy ? 48u : 32u; s.oz = s.sz ? 80u : 64u;
+  return s;
+}
+// Both children of a node at once.  Each axis quad holds (entry L, entry R, exit L, exit R): the children's planes
+// already ordered for the ray's direction.  tl / tr: entry distances clamped to 0; hit iff entry <= exit
+// (widened).  fmaxf/fminf ignore NaN (0*inf axes) => conservative.
+__device__ __forceinline__ void slab_pair_test(const SlabRay& s, float4 qx, float4 qy, float4 qz, float tmax, float& tl,
+                                               float& tr, bool& hl, bool& hr) {
+  const float t0xl = __builtin_fmaf(qx.x, s.ix, -s.nx), t0xr = __builtin_fmaf(qx.y, s.ix, -s.nx);
+  const float t1xl = __builtin_fmaf(qx.z, s.ix, -s.fx), t1xr = __builtin_fmaf(qx.w, s.ix, -s.fx);
+  const float t0yl = __builtin_fmaf(qy.x, s.iy, -s.ny), t0yr = __builtin_fmaf(qy.y, s.iy, -s.ny);
+  const float t1yl = __builtin_fmaf(qy.z, s.iy, -s.fy), t1yr = __builtin_fmaf(qy.w, s.iy, -s.fy);
+  const float t0zl = __builtin_fmaf(qz.x, s.iz, -s.nz), t0zr = __builtin_fmaf(qz.y, s.iz, -s.nz);
+  const float t1zl = __builtin_fmaf(qz.z, s.iz, -s.fz), t1zr = __builtin_fmaf(qz.w, s.iz, -s.fz);
+  tl = fmaxf(fmaxf(fmaxf(t0xl, t0yl), t0zl), 0.f);
+  tr = fmaxf(fmaxf(fmaxf(t0xr, t0yr), t0zr), 0.f);
+  const float fl = fminf(fminf(fminf(t1xl, t1yl), t1zl), tmax);
+  const float fr = fminf(fminf(fminf(t1xr, t1yr), t1zr), tmax);
+  hl = tl <= fl * 1.0000019f + 1e-30f;
+  hr = tr <= fr * 1.0000019f + 1e-30f;
+}
+// 64-B node (l_lo l_hi r_lo r_hi as three float4) -> direction-ordered plane quads by select
+__device__ __forceinline__ void slab_select(const SlabRay& s, float4 q0, float4 q1, float4 q2, float4& qx, float4& qy,
+                                            float4& qz) {
+  qx = s.sx ? float4{q0.w, q2.y, q0.x, q1.z} : float4{q0.x, q1.z, q0.w, q2.y};
+  qy = s.sy ? float4{q1.x, q2.z, q0.y, q1.w} : float4{q0.y, q1.w, q1.x, q2.z};
+  qz = s.sz ? float4{q1.y, q2.w, q0.z, q2.x} : float4{q0.z, q2.x, q1.y, q2.w};
+}
+
 // ----------------------------------------------------------------------------------------------- scene accessors
 // Where the traversal data lives.  GlobalAcc reads HBM/L2 through the vector cache; LdsAcc reads a
 // per-workgroup copy of the whole scene (nodes + 64-B sphere records) in LDS.
@@ -163,9 +217,11 @@ struct GlobalAcc {
   const BvhNode* nodes;
   const Prim* prims;
   static constexpr bool kSpheresOnly = false;
-  __device__ __forceinline__ void node(int32_t i, float4& q0, float4& q1, float4& q2, int2& ch) const {
+  __device__ __forceinline__ int32_t root(int32_t r) const { return r; }
+  __device__ __forceinline__ void node_slabs(int32_t i, const SlabRay& s, float4& qx, float4& qy, float4& qz,
+                                             int2& ch) const {
     const float4* np = reinterpret_cast<const float4*>(nodes + i);
-    q0 = np[0]; q1 = np[1]; q2 = np[2];
+    slab_select(s, np[0], np[1], np[2], qx, qy, qz);
     ch = *reinterpret_cast<const int2*>(&np[3]);
   }
   __device__ __forceinline__ uint32_t type(int32_t pi) const { return prims[pi].type; }
@@ -176,17 +232,16 @@ struct GlobalAcc {
   __device__ __forceinline__ const Prim& full(int32_t pi) const { return prims[pi]; }
   __device__ __forceinline__ uint32_t mat(int32_t pi) const { return prims[pi].mat; }
 };
-// NSTRIDE = node stride in 16-byte units: 4 (dense, global memory) or 5 (LDS copy padded to 80 B so that the
-// per-lane random node fetches of a ds_read_b128 lane group spread over 16 bank offsets instead of 4).
-template <class SphT, int NSTRIDE = 4>  // SphT = const SphereRec* in global or LDS address space (inferred after inlining)
-struct SphereAccT {
+// spheres-only scene in global memory: dense 64-B nodes + 64-B sphere records
+struct SphereAcc {
   const float4* nodes;
-  SphT spheres;
-  const Prim* prims_unused;
+  const SphereRec* spheres;
   static constexpr bool kSpheresOnly = true;
-  __device__ __forceinline__ void node(int32_t i, float4& q0, float4& q1, float4& q2, int2& ch) const {
-    const float4* np = nodes + NSTRIDE * i;
-    q0 = np[0]; q1 = np[1]; q2 = np[2];
+  __device__ __forceinline__ int32_t root(int32_t r) const { return r; }
+  __device__ __forceinline__ void node_slabs(int32_t i, const SlabRay& s, float4& qx, float4& qy, float4& qz,
+                                             int2& ch) const {
+    const float4* np = nodes + 4 * i;
+    slab_select(s, np[0], np[1], np[2], qx, qy, qz);
     float4 q3 = np[3];
     ch = {__float_as_int(q3.x), __float_as_int(q3.y)};
   }
@@ -195,10 +250,50 @@ struct SphereAccT {
     const SphereRec& S = spheres[pi];
     return {{S.c0[0], S.c0[1], S.c0[2]}, {S.c1[0], S.c1[1], S.c1[2]}, S.r, S.type, S.mat};
   }
-  __device__ __forceinline__ const Prim& full(int32_t) const { return *prims_unused; }
+  __device__ __forceinline__ const Prim& full(int32_t) const { return *reinterpret_cast<const Prim*>(spheres); }  // never called
   __device__ __forceinline__ uint32_t mat(int32_t pi) const { return spheres[pi].mat; }
 };
-using SphereAcc = SphereAccT<const SphereRec*>;
+// Whole spheres-only scene in LDS (k_fused).  Nodes are re-laid out as 112-byte "slab nodes": per axis the four
+// planes of the two children are stored twice, once per ray direction, as (entry L, entry R, exit L, exit R), so a
+// ray fetches its direction-ordered planes with one ds_read_b128 per axis at base + {ox, oy, oz} and spends no
+// per-step selects (12 v_cndmask per step in the 64-B layout):
+//   +0  x forward  [lo L, lo R, hi L, hi R]     +16 x backward [hi L, hi R, lo L, lo R]
+//   +32 y forward                               +48 y backward
+//   +64 z forward                               +80 z backward          +96 children (left, right)   +104 pad
+// Inner-node references are pre-scaled to 16-byte units (index * 7) in the child links, the root and the stack,
+// so a node's LDS address is ref << 4.
+struct SlabLdsAcc {
+  const unsigned char* nodes;
+  const SphereRec* spheres;
+  static constexpr bool kSpheresOnly = true;
+  __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
+  __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
+                                             int2& ch) const {
+    const unsigned char* b = nodes + ((uint32_t)ref << 4);
+    qx = *reinterpret_cast<const float4*>(b + s.ox);
+    qy = *reinterpret_cast<const float4*>(b + s.oy);
+    qz = *reinterpret_cast<const float4*>(b + s.oz);
+    ch = *reinterpret_cast<const int2*>(b + 96);
+  }
+  __device__ __forceinline__ uint32_t type(int32_t pi) const { return spheres[pi].type; }
+  __device__ __forceinline__ PrimGeom sphere(int32_t pi) const {
+    const SphereRec& S = spheres[pi];
+    return {{S.c0[0], S.c0[1], S.c0[2]}, {S.c1[0], S.c1[1], S.c1[2]}, S.r, S.type, S.mat};
+  }
+  __device__ __forceinline__ const Prim& full(int32_t) const { return *reinterpret_cast<const Prim*>(spheres); }  // never called
+  __device__ __forceinline__ uint32_t mat(int32_t pi) const { return spheres[pi].mat; }
+};
+__device__ __forceinline__ void slab_node_store(unsigned char* l_nodes, int i, const BvhNode& n) {
+  float4* w = reinterpret_cast<float4*>(l_nodes + (size_t)i * RT_SLAB_NODE_BYTES);
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    w[2 * a] = float4{n.l_lo[a], n.r_lo[a], n.l_hi[a], n.r_hi[a]};
+    w[2 * a + 1] = float4{n.l_hi[a], n.r_hi[a], n.l_lo[a], n.r_lo[a]};
+  }
+  const int32_t k = RT_SLAB_NODE_BYTES / 16;
+  const int32_t l = n.left >= 0 ? n.left * k : n.left, r = n.right >= 0 ? n.right * k : n.right;
+  w[6] = float4{__int_as_float(l), __int_as_float(r), 0.f, 0.f};
+}
 
 // ----------------------------------------------------------------------------------------------- intersection
 struct HitInfo {
@@ -314,45 +409,6 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
   return true;
 }
 
-// Per-ray constants of the f32 slab test.  t = plane*inv - (o*inv); the origin's f32 rounding error
-// |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
-// coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
-struct SlabRay {
-  float ix, iy, iz;
-  float nx, ny, nz;
-  float fx, fy, fz;
-  bool sx, sy, sz;  // direction negative on axis
-};
-__device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
-  SlabRay s;
-  float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-  s.ix = __builtin_amdgcn_rcpf((float)d.x);
-  s.iy = __builtin_amdgcn_rcpf((float)d.y);
-  s.iz = __builtin_amdgcn_rcpf((float)d.z);
-  float ax = ox * s.ix, ay = oy * s.iy, az = oz * s.iz;
-  const float E = 9.5367431640625e-07f;  // 2^-20: > 8 ulp, covers o / d / rcp / fma rounding
-  float ex = __builtin_fabsf(ax) * E, ey = __builtin_fabsf(ay) * E, ez = __builtin_fabsf(az) * E;
-  s.nx = ax + ex; s.ny = ay + ey; s.nz = az + ez;
-  s.fx = ax - ex; s.fy = ay - ey; s.fz = az - ez;
-  s.sx = s.ix < 0.f; s.sy = s.iy < 0.f; s.sz = s.iz < 0.f;
-  return s;
-}
-// entry distance (clamped to 0) in tn; hit iff tn <= tf (widened)
-__device__ __forceinline__ bool slab_test(const SlabRay& s, float lox, float loy, float loz, float hix, float hiy,
-                                          float hiz, float tmax, float& tn) {
-  float nx = s.sx ? hix : lox, fx = s.sx ? lox : hix;
-  float ny = s.sy ? hiy : loy, fy = s.sy ? loy : hiy;
-  float nz = s.sz ? hiz : loz, fz = s.sz ? loz : hiz;
-  float t0x = __builtin_fmaf(nx, s.ix, -s.nx), t1x = __builtin_fmaf(fx, s.ix, -s.fx);
-  float t0y = __builtin_fmaf(ny, s.iy, -s.ny), t1y = __builtin_fmaf(fy, s.iy, -s.fy);
-  float t0z = __builtin_fmaf(nz, s.iz, -s.nz), t1z = __builtin_fmaf(fz, s.iz, -s.fz);
-  // fmaxf/fminf ignore NaN (0*inf axes) => conservative
-  tn = fmaxf(fmaxf(fmaxf(t0x, t0y), t0z), 0.f);
-  float tf = fminf(fminf(fminf(t1x, t1y), t1z), tmax);
-  return tn <= tf * 1.0000019f + 1e-30f;
-}
-
-
 // Resumable traversal state: one ray's walk through the BVH can be advanced one inner-node step or one leaf test
 // at a time, so a wave can interleave lanes that are at different stages (k_fused's scheduler) or simply run it
 // to completion (traverse()).
@@ -403,12 +459,12 @@ __device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int strid
 // precondition: ts.cur >= 0
 template <class Acc, class StackT>
 __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT* stack, int stride) {
-  float4 q0, q1, q2;
+  float4 qx, qy, qz;
   int2 ch;
-  acc.node(ts.cur, q0, q1, q2, ch);
+  acc.node_slabs(ts.cur, ts.s, qx, qy, qz, ch);
   float tl, tr;
-  bool hl = slab_test(ts.s, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ts.tmax32, tl);
-  bool hr = slab_test(ts.s, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ts.tmax32, tr);
+  bool hl, hr;
+  slab_pair_test(ts.s, qx, qy, qz, ts.tmax32, tl, tr, hl, hr);
   const bool left_first = tl <= tr;
   const bool take_left = hl && (!hr || left_first);
   if (hl && hr) trav_push(ts, left_first ? ch.y : ch.x, stack, stride);
@@ -442,33 +498,6 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
     ts.tmax32 = __double2float_ru(t);
   }
   trav_pop(ts, stack, stride);
-}
-
-// Advance the traversals of the participating lanes in while-while form until fewer than `min_lanes` of them are
-// still walking (wave-uniform exit).  min_lanes = 1 runs every traversal to completion; a larger value hands the
-// wave back early so that finished lanes can be shaded / re-launched while the stragglers keep their state.
-template <class Acc, class StackT, bool COUNT>
-__device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, bool participating, uint32_t features,
-                                                d3 o, d3 d, double time, double tmin, StackT* stack, int stride,
-                                                TravCounters* cnt, PathRng& rng, uint32_t min_lanes) {
-  while (true) {
-    const bool busy = participating && ts.cur != RT_DONE;
-    if ((uint32_t)__popcll(__ballot(busy)) < min_lanes) break;
-    if (busy) {
-      uint64_t t0 = 0;
-      if (COUNT) t0 = now_cycles();
-      while (ts.cur >= 0) {
-        if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
-        node_step(acc, ts, stack, stride);
-      }
-      if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
-      if (ts.cur != RT_DONE) {
-        if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
-        leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
-        if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
-      }
-    }
-  }
 }
 
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short

@@ -36,7 +36,7 @@ struct PassParams {
 
 __device__ __forceinline__ GlobalAcc global_acc(const Scene& sc) { return GlobalAcc{sc.nodes, sc.prims}; }
 __device__ __forceinline__ SphereAcc sphere_acc(const Scene& sc) {
-  return SphereAcc{reinterpret_cast<const float4*>(sc.nodes), sc.spheres, sc.prims};
+  return SphereAcc{reinterpret_cast<const float4*>(sc.nodes), sc.spheres};
 }
 
 // ------------------------------------------------------------------------------------------------ wavefront mode
@@ -192,10 +192,8 @@ struct FusedParams {
   uint32_t tiles_x, n_tiles, n_units;
   uint32_t k0, k1;
   uint32_t stack_depth;
-  uint32_t kn, kl, ks;  // scheduler thresholds of k_fused_sched
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
-#define RT_LDS_NODE_STRIDE 5            // in 16-byte units (80 B), see SphereAccT
 
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2 };
 
@@ -207,16 +205,16 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
 
 template <int KIND> struct AccOf;
 template <> struct AccOf<KIND_SPHERES_LDS> {
-  using type = SphereAccT<const SphereRec*, RT_LDS_NODE_STRIDE>;
-  static __device__ __forceinline__ type make(const Scene& sc, const float4* ln, const SphereRec* ls) { return type{ln, ls, sc.prims}; }
+  using type = SlabLdsAcc;
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls) { return type{ln, ls}; }
 };
 template <> struct AccOf<KIND_SPHERES_GLOBAL> {
   using type = SphereAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return sphere_acc(sc); }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return sphere_acc(sc); }
 };
 template <> struct AccOf<KIND_GENERIC> {
   using type = GlobalAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const float4*, const SphereRec*) { return global_acc(sc); }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return global_acc(sc); }
 };
 
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
@@ -230,14 +228,13 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [accumulators][stack]
   size_t off = 0;
-  float4* l_nodes = reinterpret_cast<float4*>(smem);
+  unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
   if (KIND == KIND_SPHERES_LDS) {
-    off += (size_t)sc.n_nodes * RT_LDS_NODE_STRIDE * 16;
+    off += RT_SLAB_REGION_BYTES(sc.n_nodes);
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
     off += (size_t)sc.n_prims * 64;
-    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
-    for (int i = threadIdx.x; i < sc.n_nodes * 4; i += BLOCK) l_nodes[(i >> 2) * RT_LDS_NODE_STRIDE + (i & 3)] = gn[i];
+    for (int i = threadIdx.x; i < sc.n_nodes; i += BLOCK) slab_node_store(l_nodes, i, sc.nodes[i]);
     const float4* gs = reinterpret_cast<const float4*>(sc.spheres);
     float4* ls = reinterpret_cast<float4*>(l_sph);
     for (int i = threadIdx.x; i < sc.n_prims * 4; i += BLOCK) ls[i] = gs[i];
@@ -269,10 +266,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
     f3 thr = {1.f, 1.f, 1.f};
     uint32_t depth = 0, lpix = 0;
     PathRng rng = {0, 0};
-    TravState ts;
-    ts.cur = RT_DONE; ts.sp = 0; ts.top = RT_DONE; ts.best_prim = -1; ts.tmax32 = 0.f; ts.best_t = 0; ts.a = 1; ts.inv_a = 1;
-    ts.s = SlabRay{0, 0, 0, 0, 0, 0, 0, 0, 0, false, false, false};
-    bool fresh = false;  // wave-uniform: some lane received a new ray since the last traversal call
     while (true) {
       // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
       unsigned long long need = __ballot(!active);
@@ -291,29 +284,20 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
             depth = 0;
             lpix = pit;
             active = true;
-            trav_init(ts, sc.root, o, d);
-            my_rays++;
           }
         }
         next = min(total, next + (uint32_t)__popcll(need));
-        fresh = true;
       }
       if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
       if (__ballot(active) == 0ull) {
         if (next >= total) break;
         continue;
       }
-      // ---- traverse: hand the wave back once fewer than kn lanes are still walking (stragglers keep their
-      //      TravState and continue next round next to the re-launched lanes); with nothing new to launch, finish
-      traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
-                                                                 &tc, rng, fresh ? fp.kn : 1u);
-      // ---- shade the lanes whose traversal is complete
-      const bool ready = active && ts.cur == RT_DONE;
-      fresh = __ballot(ready) != 0ull;
-      if (ready) {
-        HitInfo hit;
-        hit.t = ts.best_t;
-        hit.prim = ts.best_prim;
+      // ---- one bounce for every lane that carries a path: closest hit, then shade
+      if (active) {
+        my_rays++;
+        HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
+                                                                          stack, BLOCK, &tc, rng);
         if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
         ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
         if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
@@ -328,8 +312,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
             active = false;  // mod.rs:195-197: black
           } else {
             o = so.o; d = so.d; thr = so.thr;
-            trav_init(ts, sc.root, o, d);
-            my_rays++;
           }
         }
       }
@@ -356,168 +338,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
                    tc.t_nodes, tc.t_prims, st_tshade, st_tregen, st_ttotal};
     for (int k = 0; k < 13; k++) {
       float x = v[k];
-      for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
-      if (lane == 0) atomicAdd(&dbg[k], x);
-    }
-  }
-}
-
-// ---- scheduled variant of the fused kernel -------------------------------------------------------------------
-// Same work units, pool, RNG streams and accumulators as k_fused, but the wave no longer runs
-// "traverse everything, then shade everything": every lane carries a resumable traversal (TravState) and the wave
-// picks, per iteration, the phase with enough waiting lanes — an inner-node step (N), a leaf test (L) or
-// shade + regenerate (S).  A lane whose traversal ends early is reshaded and re-launched while its neighbours
-// keep walking the tree, which is what lifts the SIMD lane utilisation of the node loop (profiles/: 32 % in
-// k_fused).  Thresholds kn / kl / ks are runtime parameters (FusedParams).
-template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
-__global__ __launch_bounds__(BLOCK) void k_fused_sched(Scene sc, Camera cam, FusedParams fp,
-                                                       uint32_t* __restrict__ unit_counter,
-                                                       unsigned long long* __restrict__ fbacc,
-                                                       unsigned long long* __restrict__ ray_total,
-                                                       float* __restrict__ dbg = nullptr) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  size_t off = 0;
-  float4* l_nodes = reinterpret_cast<float4*>(smem);
-  SphereRec* l_sph = nullptr;
-  if (KIND == KIND_SPHERES_LDS) {
-    off += (size_t)sc.n_nodes * RT_LDS_NODE_STRIDE * 16;
-    l_sph = reinterpret_cast<SphereRec*>(smem + off);
-    off += (size_t)sc.n_prims * 64;
-    const float4* gn = reinterpret_cast<const float4*>(sc.nodes);
-    for (int i = threadIdx.x; i < sc.n_nodes * 4; i += BLOCK) l_nodes[(i >> 2) * RT_LDS_NODE_STRIDE + (i & 3)] = gn[i];
-    const float4* gs = reinterpret_cast<const float4*>(sc.spheres);
-    float4* ls = reinterpret_cast<float4*>(l_sph);
-    for (int i = threadIdx.x; i < sc.n_prims * 4; i += BLOCK) ls[i] = gs[i];
-  }
-  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
-  off += (size_t)(BLOCK / 64) * 192 * 8;
-  StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
-  if (KIND == KIND_SPHERES_LDS) __syncthreads();
-  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph);
-
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t KN = fp.kn, KL = fp.kl, KS = fp.ks;
-  unsigned long long my_rays = 0;
-  float st[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // STATS: lane-work / wave-trips of N, L, S, R
-  while (true) {
-    uint32_t u = 0;
-    if (lane == 0) u = atomicAdd(unit_counter, 1u);
-    u = __shfl(u, 0, 64);
-    if (u >= fp.n_units) break;
-    const uint32_t tile = u % fp.n_tiles, chunk = u / fp.n_tiles;
-    const uint32_t x0 = (tile % fp.tiles_x) * 8, y0 = (tile / fp.tiles_x) * 8;
-    const uint32_t k_lo = chunk * fp.Ku;
-    const uint32_t k_n = min(fp.Ku, fp.K - k_lo);
-    const uint32_t total = 64u * k_n;
-    l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t next = 0;  // wave-uniform pool cursor
-    bool active = false;
-    d3 o = {0, 0, 0}, d = {0, 0, 0};
-    double time = 0;
-    f3 thr = {1.f, 1.f, 1.f};
-    uint32_t depth = 0, lpix = 0;
-    PathRng rng = {0, 0};
-    TravState ts;
-    ts.cur = RT_DONE; ts.sp = 0; ts.top = RT_DONE; ts.best_prim = -1; ts.tmax32 = 0.f; ts.best_t = 0; ts.a = 1; ts.inv_a = 1;
-    ts.s = SlabRay{0, 0, 0, 0, 0, 0, 0, 0, 0, false, false, false};
-    uint32_t kn_eff = KN;
-    while (true) {
-      // tight inner-node loop: keep stepping while enough lanes are walking the tree
-      uint32_t nN;
-      while (true) {
-        const bool inN = active && ts.cur >= 0;
-        nN = (uint32_t)__popcll(__ballot(inN));
-        if (nN < kn_eff) break;
-        if (inN) {
-          if (STATS) { st[0] += 1.f; st[1] += wave_share(); }
-          node_step(acc, ts, stack, BLOCK);
-        }
-      }
-      kn_eff = KN;
-      int act;  // 1 = leaf test, 2 = shade + regenerate
-      {
-        const bool inL = active && ts.cur < 0 && ts.cur != RT_DONE;
-        const uint32_t nL = (uint32_t)__popcll(__ballot(inL));
-        const uint32_t nS = (uint32_t)__popcll(__ballot(active && ts.cur == RT_DONE));
-        const uint32_t nR = min((uint32_t)__popcll(__ballot(!active)), total - next);
-        if (nL >= KL) act = 1;
-        else if (nS + nR >= KS) act = 2;
-        else if (nN > 0) { kn_eff = 1; continue; }  // not enough waiting work: keep walking with who is left
-        else if (nL > 0) act = 1;
-        else if (nS + nR > 0) act = 2;
-        else break;
-      }
-      if (act == 1) {
-        if (active && ts.cur < 0 && ts.cur != RT_DONE) {
-          if (STATS) { st[2] += 1.f; st[3] += wave_share(); }
-          leaf_step(acc, ts, F, o, d, time, RT_TMIN, stack, BLOCK, rng);
-        }
-      } else {
-        if (active && ts.cur == RT_DONE) {
-          if (STATS) { st[4] += 1.f; st[5] += wave_share(); }
-          HitInfo hit;
-          hit.t = ts.best_t;
-          hit.prim = ts.best_prim;
-          ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
-          if (!so.alive) {
-            atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
-            atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
-            atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
-            active = false;
-          } else {
-            depth++;
-            if (depth >= cam.max_depth) {
-              active = false;  // mod.rs:195-197: black
-            } else {
-              o = so.o; d = so.d; thr = so.thr;
-              trav_init(ts, sc.root, o, d);
-              my_rays++;
-            }
-          }
-        }
-        // regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
-        unsigned long long need = __ballot(!active);
-        if (need && next < total) {
-          uint32_t j = next + wave_prefix(need);
-          if (!active && j < total) {
-            uint32_t pit = j & 63u, ks = j >> 6;
-            uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
-            if (px < cam.width && py < cam.height) {
-              if (STATS) { st[6] += 1.f; st[7] += wave_share(); }
-              uint32_t pixel = py * cam.width + px;
-              uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
-              generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
-              thr = {1.f, 1.f, 1.f};
-              depth = 0;
-              lpix = pit;
-              active = true;
-              trav_init(ts, sc.root, o, d);
-              my_rays++;
-            }
-          }
-          next = min(total, next + (uint32_t)__popcll(need));
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {  // flush the tile's accumulators
-      uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
-      if (px < cam.width && py < cam.height) {
-        size_t p = ((size_t)py * cam.width + px) * 3;
-        unsigned long long a0 = l_acc[lane * 3], a1 = l_acc[lane * 3 + 1], a2 = l_acc[lane * 3 + 2];
-        if (a0) atomicAdd(&fbacc[p], a0);
-        if (a1) atomicAdd(&fbacc[p + 1], a1);
-        if (a2) atomicAdd(&fbacc[p + 2], a2);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  for (int off2 = 32; off2 > 0; off2 >>= 1) my_rays += __shfl_down(my_rays, off2, 64);
-  if (lane == 0 && my_rays) atomicAdd(ray_total, my_rays);
-  if (STATS && dbg) {
-    for (int k = 0; k < 8; k++) {
-      float x = st[k];
       for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
       if (lane == 0) atomicAdd(&dbg[k], x);
     }
@@ -615,8 +435,6 @@ struct rt_ctx {
   int fused_lds = 1;         // keep the scene in LDS when it fits
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
   int fused_block = 1024;    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
-  int fused_sched = 0;       // 1 = k_fused_sched (phase scheduler), 0 = k_fused (bounce-synchronous)
-  int sched_kn = 1, sched_kl = 8, sched_ks = 24;  // kn also = early hand-back threshold of k_fused (1 = off)
   float* d_dbg = nullptr;
   WorkBuffers wb;
   uint32_t* d_unit_counter = nullptr;
@@ -779,11 +597,6 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "fused_block") {
     if (value != 1024 && value != 512 && value != 256) return fail(ctx, RT_E_INVALID_ARG, "fused_block must be 1024, 512 or 256");
     ctx->fused_block = (int)value;
-  } else if (k == "fused_sched") {
-    ctx->fused_sched = value ? 1 : 0;
-  } else if (k == "sched_kn" || k == "sched_kl" || k == "sched_ks") {
-    if (value < 1 || value > 64) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 1..64");
-    (k == "sched_kn" ? ctx->sched_kn : k == "sched_kl" ? ctx->sched_kl : ctx->sched_ks) = (int)value;
   } else {
     return fail(ctx, RT_E_INVALID_ARG, "rt_set_option: unknown key " + k);
   }
@@ -1224,7 +1037,7 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
-  auto kern = ctx->fused_sched ? k_fused_sched<F, KIND, BLOCK, StackT, STATS> : k_fused<F, KIND, BLOCK, StackT, STATS>;
+  auto kern = k_fused<F, KIND, BLOCK, StackT, STATS>;
   HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
   int per_cu = 0;
@@ -1271,12 +1084,11 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
-  fp.kn = (uint32_t)ctx->sched_kn; fp.kl = (uint32_t)ctx->sched_kl; fp.ks = (uint32_t)ctx->sched_ks;
   const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
-  const bool small_ids = scene->view.n_nodes < 32000 && scene->view.n_prims < 32000;
+  const bool small_ids = (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768 && scene->view.n_prims < 32000;  // int16 stack entries
   int rc;
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
-  const size_t lds_scene = (size_t)scene->view.n_nodes * RT_LDS_NODE_STRIDE * 16 + (size_t)scene->view.n_prims * 64;
+  const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64;
   const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   StageTimer tm(ctx, st);
   tm.begin();

@@ -29,27 +29,16 @@ def run(stats, **opts):
             lane, wave = d[2 * i], d[2 * i + 1]
             out[n] = {"per_ray": round(lane / st["rays"], 3), "trips_x64_per_ray": round(wave * 64 / st["rays"], 3),
                       "lane_util": round(lane / (64 * wave), 3) if wave else None}
+        if d[12] > 0:  # cycle shares of the phases (s_memtime deltas, per wave)
+            out["cycles"] = {n: round(d[8 + i] / d[12], 3) for i, n in enumerate(["node", "leaf", "shade", "regen"])}
     print(json.dumps(out), flush=True)
 
 
-run(False, fused_sched=0)
+run(False)
 if "--occ" in sys.argv:
-    run(False, fused_sched=0, fused_block=512)
-    run(False, fused_sched=0, fused_block=256)
-    run(False, fused_sched=0, fused_block=1024, fused_lds=0)
+    run(False, fused_block=512)
+    run(False, fused_block=256)
+    run(False, fused_block=1024, fused_lds=0)
     ctx.set_option("fused_lds", 1)
 if "--stats" in sys.argv:
-    run(True, fused_sched=0)
-    run(False, fused_sched=1, sched_kn=24, sched_kl=8, sched_ks=24)
-    run(True, fused_sched=1, sched_kn=24, sched_kl=8, sched_ks=24)
-if "--sweep" in sys.argv:
-    for kn in (8, 16, 24, 32):
-        for kl in (8, 16, 24, 32):
-            for ks in (24, 32, 40, 48, 56):
-                run(False, fused_sched=1, sched_kn=kn, sched_kl=kl, sched_ks=ks)
-if "--handback" in sys.argv:  # k_fused early hand-back threshold (sched_kn doubles as it; 1 = run to completion)
-    for kn in (1, 8, 16, 24, 32, 40, 48):
-        run(False, fused_sched=0, sched_kn=kn)
-    run(True, fused_sched=0, sched_kn=1)
-    run(True, fused_sched=0, sched_kn=24)
-    run(True, fused_sched=0, sched_kn=40)
+    run(True)
