@@ -96,6 +96,7 @@ struct Hits {
 #define RT_F_QUAD 8u
 #define RT_F_MEDIUM 16u
 #define RT_F_ALL 31u
+#define RT_F_TEX_ANY 7u
 
 // ----------------------------------------------------------------------------------------------- RNG
 // Philox4x32-10 (Salmon et al., SC'11).  Counter = (pixel, sample, bounce, purpose), key = seed.
@@ -282,6 +283,28 @@ struct SlabLdsAcc {
   }
   __device__ __forceinline__ const Prim& full(int32_t) const { return *reinterpret_cast<const Prim*>(spheres); }  // never called
   __device__ __forceinline__ uint32_t mat(int32_t pi) const { return spheres[pi].mat; }
+};
+// Small general scene (quads, media, spheres) in LDS: slab nodes + the full 128-B primitive records.
+struct GenericLdsAcc {
+  const unsigned char* nodes;
+  const Prim* prims;
+  static constexpr bool kSpheresOnly = false;
+  __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
+  __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
+                                             int2& ch) const {
+    const unsigned char* b = nodes + ((uint32_t)ref << 4);
+    qx = *reinterpret_cast<const float4*>(b + s.ox);
+    qy = *reinterpret_cast<const float4*>(b + s.oy);
+    qz = *reinterpret_cast<const float4*>(b + s.oz);
+    ch = *reinterpret_cast<const int2*>(b + 96);
+  }
+  __device__ __forceinline__ uint32_t type(int32_t pi) const { return prims[pi].type; }
+  __device__ __forceinline__ PrimGeom sphere(int32_t pi) const {
+    const Prim& P = prims[pi];
+    return {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, P.f[6], P.type, P.mat};
+  }
+  __device__ __forceinline__ const Prim& full(int32_t pi) const { return prims[pi]; }
+  __device__ __forceinline__ uint32_t mat(int32_t pi) const { return prims[pi].mat; }
 };
 __device__ __forceinline__ void slab_node_store(unsigned char* l_nodes, int i, const BvhNode& n) {
   float4* w = reinterpret_cast<float4*>(l_nodes + (size_t)i * RT_SLAB_NODE_BYTES);

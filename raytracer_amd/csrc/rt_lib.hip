@@ -195,7 +195,7 @@ struct FusedParams {
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
 
-enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2 };
+enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3 };
 
 __device__ __forceinline__ unsigned long long to_fix(float v) {
   if (!(v > 0.f)) return 0ull;  // also NaN
@@ -208,6 +208,12 @@ template <> struct AccOf<KIND_SPHERES_LDS> {
   using type = SlabLdsAcc;
   static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls) { return type{ln, ls}; }
 };
+template <> struct AccOf<KIND_GENERIC_LDS> {
+  using type = GenericLdsAcc;
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp) {
+    return type{ln, reinterpret_cast<const Prim*>(lp)};
+  }
+};
 template <> struct AccOf<KIND_SPHERES_GLOBAL> {
   using type = SphereAcc;
   static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return sphere_acc(sc); }
@@ -218,7 +224,7 @@ template <> struct AccOf<KIND_GENERIC> {
 };
 
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
-__global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
+__global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
                                                  unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
   TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
@@ -230,19 +236,21 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
   size_t off = 0;
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
-  if (KIND == KIND_SPHERES_LDS) {
+  if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) {
     off += RT_SLAB_REGION_BYTES(sc.n_nodes);
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
-    off += (size_t)sc.n_prims * 64;
+    const int rec16 = KIND == KIND_SPHERES_LDS ? 4 : 8;  // record size in float4s: SphereRec 64 B / Prim 128 B
+    off += (size_t)sc.n_prims * rec16 * 16;
     for (int i = threadIdx.x; i < sc.n_nodes; i += BLOCK) slab_node_store(l_nodes, i, sc.nodes[i]);
-    const float4* gs = reinterpret_cast<const float4*>(sc.spheres);
+    const float4* gs = KIND == KIND_SPHERES_LDS ? reinterpret_cast<const float4*>(sc.spheres)
+                                                : reinterpret_cast<const float4*>(sc.prims);
     float4* ls = reinterpret_cast<float4*>(l_sph);
-    for (int i = threadIdx.x; i < sc.n_prims * 4; i += BLOCK) ls[i] = gs[i];
+    for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
   }
   unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
   off += (size_t)(BLOCK / 64) * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
-  if (KIND == KIND_SPHERES_LDS) __syncthreads();
+  if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) __syncthreads();
   const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph);
 
   const uint32_t lane = threadIdx.x & 63u;
@@ -266,6 +274,22 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
     f3 thr = {1.f, 1.f, 1.f};
     uint32_t depth = 0, lpix = 0;
     PathRng rng = {0, 0};
+    // shade one finished traversal; returns true when the path continues with a new ray in (o, d)
+    auto bounce = [&](HitInfo hit) -> bool {
+      if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
+      ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
+      if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
+      if (!so.alive) {
+        atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
+        atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
+        atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
+        return false;
+      }
+      depth++;
+      if (depth >= cam.max_depth) return false;  // mod.rs:195-197: black
+      o = so.o; d = so.d; thr = so.thr;
+      return true;
+    };
     while (true) {
       // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
       unsigned long long need = __ballot(!active);
@@ -293,27 +317,12 @@ __global__ __launch_bounds__(BLOCK) void k_fused(Scene sc, Camera cam, FusedPara
         if (next >= total) break;
         continue;
       }
-      // ---- one bounce for every lane that carries a path: closest hit, then shade
       if (active) {
+        // ---- one bounce for every lane that carries a path: closest hit, then shade
         my_rays++;
         HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
                                                                           stack, BLOCK, &tc, rng);
-        if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
-        ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
-        if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
-        if (!so.alive) {
-          atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
-          atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
-          atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
-          active = false;
-        } else {
-          depth++;
-          if (depth >= cam.max_depth) {
-            active = false;  // mod.rs:195-197: black
-          } else {
-            o = so.o; d = so.d; thr = so.thr;
-          }
-        }
+        if (!bounce(hit)) active = false;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1085,11 +1094,14 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
   const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
+  const uint32_t tex_only = scene->features & RT_F_TEX_ANY;  // texture kinds present (kernels are specialised on them)
   const bool small_ids = (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768 && scene->view.n_prims < 32000;  // int16 stack entries
   int rc;
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
   const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64;
   const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
+  const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 +
+                                  16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   StageTimer tm(ctx, st);
   tm.begin();
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
@@ -1101,11 +1113,16 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     } else if (lean && ctx->fused_block == 256) {
       rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 256, int16_t>(ctx, scene, dc, fp, lds_scene + 4 * 192 * 8 + (size_t)sdepth * 256 * 2, st);
     } else if (lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
-    else rc = launch_fused<RT_F_ALL, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else if (tex_only == RT_F_TEX_IMAGE) rc = launch_fused<RT_F_TEX_IMAGE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else rc = launch_fused<RT_F_TEX_ANY, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+  } else if (!scene->spheres_only && ctx->fused_lds && small_ids && lds_generic_1024 <= 160 * 1024) {
+    if (tex_only == 0) rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
+    else rc = launch_fused<RT_F_ALL, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
   } else {
     const size_t smem = 4 * 192 * 8 + (size_t)sdepth * 256 * 4;
     if (scene->spheres_only && lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else if (scene->spheres_only) rc = launch_fused<RT_F_ALL, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else if (scene->spheres_only) rc = launch_fused<RT_F_TEX_ANY, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else if (tex_only == 0) rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
     else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
   }
   if (rc) return rc;
