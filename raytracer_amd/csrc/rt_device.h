@@ -602,20 +602,50 @@ __device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 
 // ----------------------------------------------------------------------------------------------- textures
 // xoroshiro128+ short jump as a GF(2)-linear map: state' = XOR over the 16 state bytes of table[byte][value]
 // (the jump of random.rs:37-57 is linear, so its 128 conditional-XOR steps collapse to 16 table lookups).
-__device__ __noinline__ double noise_at_dev(const uint4* __restrict__ table, int32_t x, int32_t y, int32_t z) {  // texture.rs:148-154
-  uint64_t a = (uint64_t)(int64_t)x;
-  uint64_t b = (uint64_t)(int64_t)y + ((uint64_t)(int64_t)z << 32);
-  uint32_t w[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+// XOR of the four table rows row0..row0+3 selected by the bytes of `word` (one 32-bit quarter of the state)
+__device__ __noinline__ uint4 noise_jump_part(const uint4* __restrict__ table, uint32_t word, int row0) {
   uint4 acc = {0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    uint32_t byte = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu;
-    uint4 e = table[i * 256 + byte];
+  for (int i = 0; i < 4; i++) {
+    uint4 e = table[(row0 + i) * 256 + ((word >> (i * 8)) & 0xffu)];
     acc.x ^= e.x; acc.y ^= e.y; acc.z ^= e.z; acc.w ^= e.w;
   }
-  uint64_t s0 = (uint64_t)acc.x | ((uint64_t)acc.y << 32), s1 = (uint64_t)acc.z | ((uint64_t)acc.w << 32);
+  return acc;
+}
+__device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
+__device__ __forceinline__ double noise_value(uint4 st) {
+  uint64_t s0 = (uint64_t)st.x | ((uint64_t)st.y << 32), s1 = (uint64_t)st.z | ((uint64_t)st.w << 32);
   uint64_t r = s0 + s1;                       // next_u64 (random.rs:18-28)
   return (double)r / 18446744073709551616.0;  // next_f64 (random.rs:30-32), u64->f64 RNE
+}
+// texture.rs:148-154 for the 8 lattice corners of a cell at once.  Seed words (texture.rs:149-150):
+//   a = x as u64 (sign-extended), b = y as u64 + (z as u64 << 32)  =>  b.lo = y, b.hi = z + (y < 0 ? -1 : 0).
+// The jump is linear over GF(2), so the state splits into parts that depend on x only (2 values), on y only
+// (2 values) and on (y's sign, z) (4 values): 40 table lookups for the 8 corners instead of 128.
+// Corner k: x bit 0, z bit 1, y bit 2 (order of texture.rs:130-137).
+__device__ __forceinline__ void noise_corners_dev(const uint4* __restrict__ table, int32_t ix, int32_t iy, int32_t iz,
+                                                  double c[8]) {
+  uint4 tx[2], ty[2], tz[4];
+#pragma unroll
+  for (int dx = 0; dx < 2; dx++) {
+    const int32_t cx = (int32_t)((uint32_t)ix + (uint32_t)dx);
+    tx[dx] = xor4(noise_jump_part(table, (uint32_t)cx, 0), noise_jump_part(table, cx < 0 ? 0xffffffffu : 0u, 4));
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++) {
+    const int32_t cy = (int32_t)((uint32_t)iy + (uint32_t)dy);
+    ty[dy] = noise_jump_part(table, (uint32_t)cy, 8);
+#pragma unroll
+    for (int dz = 0; dz < 2; dz++) {
+      const uint32_t cz = (uint32_t)iz + (uint32_t)dz;
+      tz[dy * 2 + dz] = noise_jump_part(table, cz + (cy < 0 ? 0xffffffffu : 0u), 12);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int dx = k & 1, dz = (k >> 1) & 1, dy = (k >> 2) & 1;
+    c[k] = noise_value(xor4(xor4(tx[dx], ty[dy]), tz[dy * 2 + dz]));
+  }
 }
 __device__ __forceinline__ int32_t sat_i32(double v) {  // Rust `as i32`
   if (!(v == v)) return 0;
@@ -668,12 +698,7 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
       double fx = rem_euclid1(x), fy = rem_euclid1(y), fz = rem_euclid1(z);
       double xb = fx * fx * (3.0 - 2.0 * fx), yb = fy * fy * (3.0 - 2.0 * fy), zb = fz * fz * (3.0 - 2.0 * fz);
       double c[8];
-      for (int k = 0; k < 8; k++) {  // corner k: x bit0, z bit1, y bit2 (order of texture.rs:130-137)
-        int32_t cx = (int32_t)((uint32_t)ix + (uint32_t)(k & 1));
-        int32_t cz = (int32_t)((uint32_t)iz + (uint32_t)((k >> 1) & 1));
-        int32_t cy = (int32_t)((uint32_t)iy + (uint32_t)((k >> 2) & 1));
-        c[k] = noise_at_dev(sc.noise_table, cx, cy, cz);
-      }
+      noise_corners_dev(sc.noise_table, ix, iy, iz, c);
       auto lerp = [](double a, double b, double w) { return (1.0 - w) * a + w * b; };  // color.rs:62-64
       double m00 = lerp(c[0], c[1], xb), m01 = lerp(c[2], c[3], xb);
       double m10 = lerp(c[4], c[5], xb), m11 = lerp(c[6], c[7], xb);
