@@ -164,6 +164,15 @@ def main():
         fps = wl["flops_per_sample"]
         k_ms = sorted(kernel_ms)[len(kernel_ms) // 2]
         achieved = samples_per_rank * fps / (k_ms * 1e-3) / 1e12
+        # HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE / WRITE_SIZE passes of
+        # scripts/gpu_profile.sh, summarised by scripts/summarize_profile.py); only c2 is profiled
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if args.workload == "c2" and world == 1 and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                der = json.load(f).get("derived", {})
+            if "hbm_write_bytes" in der and "hbm_fetch_bytes_x2_upper" in der:
+                traffic = der["hbm_fetch_bytes_x2_upper"] + der["hbm_write_bytes"]
         out = {
             "metric": "Msamples/sec (pixels x spp)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -174,8 +183,11 @@ def main():
                        "spp_per_gpu": host_scene.spp, "samples_per_step": samples_per_rank * world,
                        "parallelism": f"sample-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / VALU_FP32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "render pipeline (k_generate + k_intersect + k_shade + k_accumulate), per rt_render call",
+                         "frac": achieved / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 upper bound + WRITE_SIZE, "
+                                         "profiles/pmc_latest.json); the kernel is compute-bound, scene and path "
+                                         "state live in LDS / registers",
+                         "kernel": "k_fused (persistent fused path-tracing kernel), per rt_render_device call",
                          "kernel_ms_per_step": k_ms, "algorithmic_flops_per_sample": fps,
                          "rays_per_sample": stats["rays"] / max(stats["paths"], 1)},
         }

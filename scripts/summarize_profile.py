@@ -6,14 +6,23 @@ os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
 out = {"command": "rocprofv3 --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline (one pass per group)",
        "kernel": None, "counters": {}}
+launches = {}
 for d in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write", "pmc_l2"):
     p = os.path.join(src, d, "p_counter_collection.csv")
     if not os.path.exists(p):
         continue
+    seen = set()
     for r in csv.DictReader(open(p)):
         if "k_fused" in r["Kernel_Name"] or "k_intersect" in r["Kernel_Name"] or "k_shade" in r["Kernel_Name"]:
             out["kernel"] = out["kernel"] or r["Kernel_Name"].split("(")[0]
             out["counters"][r["Counter_Name"]] = out["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            seen.add(r["Dispatch_Id"])
+    launches[d] = len(seen)
+# bench.py --steps 1 --warmup 0 launches the render kernel twice (timed step + the kernel-time replay): per-launch values
+n_launch = max(launches.values()) if launches else 1
+out["launches_profiled"] = n_launch
+out["counters"] = {k: v / n_launch for k, v in out["counters"].items()}
+out["note"] = "counter values are PER LAUNCH (sum over the profiled launches / launches_profiled)"
 c = out["counters"]
 der = {}
 if "SQ_INSTS_VALU" in c:
@@ -29,5 +38,6 @@ if "TCC_HIT_sum" in c:
     der["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
 out["derived"] = der
 json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
 print(json.dumps(der, indent=1))
 print(open(f"profiles/{tag}_kernel_stats.csv").read()[:700])
