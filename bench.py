@@ -44,23 +44,24 @@ WORKLOADS = {
 
 
 def cpu_baseline(scene, width, depth, texels=None):
-    """Oracle (kind 'port') on a bounded sample of the same workload: same frame, uniform 3x3 = 9 spp."""
+    """Oracle (kind 'port') on a bounded sample of the same workload (about 10-20 s of wall time on 16 threads):
+    the same frame at the config's own 100 spp for C2 (width 1200), 16 spp for the 1920-wide frames, 1 spp at 4K."""
     from oracle_lib import OracleScene
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share is 16
-    sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", 9 if width <= 1920 else 1, depth, texels=texels)
+    cspp = 100 if width <= 1200 else (16 if width <= 1920 else 1)
+    sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", cspp, depth, texels=texels)
     r = sc.render(threads=threads)
-    cspp = 9 if width <= 1920 else 1
     n = sc.width * sc.height * cspp
     # 1-thread figure on a sub-window (the reference's Arc refcount contention makes it scale sub-linearly)
-    win = (0, sc.height // 2 // 32 * 32, sc.width, 64)
+    win = (0, sc.height // 2 // 32 * 32, sc.width, 32)
     r1 = sc.render(threads=1, window=win)
-    n1 = min(64, sc.height - win[1]) * sc.width * cspp
+    n1 = min(32, sc.height - win[1]) * sc.width * cspp
     return {
         "value": n / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": f"{scene} {sc.width}x{sc.height}, uniform {cspp} spp, depth {depth}: {n} samples, "
                   f"{r['seconds']:.2f} s",
         "one_thread_value": n1 / r1["seconds"] / 1e6,
-        "one_thread_sample": f"rows {win[1]}..{win[1] + 64}, {n1} samples, {r1['seconds']:.2f} s",
+        "one_thread_sample": f"rows {win[1]}..{win[1] + 32}, {n1} samples, {r1['seconds']:.2f} s",
     }
 
 

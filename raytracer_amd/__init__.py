@@ -132,6 +132,8 @@ def hostlib():
     H.rth_scene_spp.restype = C.c_uint64
     H.rth_scene_render.argtypes = [vp, vp, C.c_uint64, C.c_char_p, vp, vp]
     H.rth_scene_render_partial.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
+    H.rth_scene_render_progressive.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, vp, vp,
+                                               C.POINTER(C.c_uint64)]
     H.rth_rng_next_f64_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp]
     _host = H
     return H
@@ -297,6 +299,33 @@ class Scene:
         if rc != 0:
             raise RuntimeError(self.H.rth_last_error().decode())
         return frame, tiles
+
+    def render_progressive(self, ctx, passes, seed=0x853C49E6748FEA9B, checkpoint_path=None, ppm_path=None,
+                           on_tile=None):
+        """Camera::render_progressive: every tile is re-sent after each of `passes` sample passes (live preview),
+        sums are checkpointed to `checkpoint_path` after each pass and a matching checkpoint is resumed.
+        Returns (last frame (H, W, 3) f64, passes rendered by this call, tile messages received)."""
+        if not getattr(ctx, "h", None):
+            raise RuntimeError("GPU backend is required (no CPU fallback)")
+        frame = np.zeros((self.height, self.width, 3), dtype=np.float64)
+        count = [0]
+
+        def cb(_user, top, left, h, w, ptr):
+            arr = np.ctypeslib.as_array(ptr, shape=(h * w * 3,)).reshape(h, w, 3)
+            frame[top:top + h, left:left + w] = arr
+            count[0] += 1
+            if on_tile is not None and on_tile(top, left, h, w, arr) is False:
+                return 0
+            return 1
+
+        cfn = TILE_CB(cb)
+        n = C.c_uint64(0)
+        rc = self.H.rth_scene_render_progressive(self.h, ctx.h, seed, passes,
+                                                 checkpoint_path.encode() if checkpoint_path else None,
+                                                 ppm_path.encode() if ppm_path else None, cfn, None, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(self.H.rth_last_error().decode())
+        return frame, int(n.value), count[0]
 
     def render_partial(self, ctx, seed, rank, world_size):
         out = np.zeros((self.height, self.width, 3), dtype=np.float32)

@@ -101,6 +101,33 @@ int rth_scene_render(rth_scene* s, rt_ctx* ctx, uint64_t seed, const char* ppm_p
   }
 }
 
+// Camera::render_progressive: tiles after every pass, optional checkpoint/resume.  *passes_rendered (may be NULL)
+// receives the number of passes rendered by this call.
+int rth_scene_render_progressive(rth_scene* s, rt_ctx* ctx, uint64_t seed, uint64_t passes, const char* checkpoint_path,
+                                 const char* ppm_path, rth_tile_cb cb, void* user, uint64_t* passes_rendered) {
+  try {
+    RenderTarget t;
+    t.ctx = ctx;
+    t.seed = seed;
+    if (ppm_path) t.ppm_path = ppm_path;
+    TileSender sender = [&](Tile&& tile) -> bool {
+      if (!cb) return true;
+      auto& [tl, rect, colors] = tile;
+      return cb(user, tl.first, tl.second, rect.first, rect.second, reinterpret_cast<const double*>(colors.data())) != 0;
+    };
+    size_t n = s->scene.camera.render_progressive(*s->scene.world, sender, t, (size_t)passes,
+                                                  checkpoint_path ? checkpoint_path : "");
+    if (passes_rendered) *passes_rendered = n;
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  } catch (...) {
+    g_err = "unknown exception";
+    return -1;
+  }
+}
+
 // un-normalised linear sums of rank's sample subset (W*H*3 f32) for an external reduce
 int rth_scene_render_partial(rth_scene* s, rt_ctx* ctx, uint64_t seed, uint32_t rank, uint32_t world_size, float* out) {
   try {

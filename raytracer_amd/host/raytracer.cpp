@@ -389,33 +389,114 @@ std::vector<float> Camera::render_partial_sums(const Hittable& world, const Rend
   return sums;
 }
 
+// mod.rs:64-78,102-114: resolve the sums (mean, gamma 2.2) and send the same 32x32 tile tuples, in tile-index order.
+// Returns false when the receiver hung up.
+static bool send_tiles(const Camera& cam, rt_ctx* ctx, const std::vector<float>& sums, size_t samples,
+                       const TileSender& sender, std::vector<Color>& image_buffer) {
+  const size_t W = cam.image_width, H = cam.image_height, pixel_count = W * H;
+  std::vector<double> rgb(pixel_count * 3);
+  check(ctx, rt_resolve(ctx, sums.data(), (uint32_t)W, (uint32_t)H, (uint32_t)samples, 2.2, rgb.data(), nullptr),
+        "rt_resolve");
+  image_buffer.resize(pixel_count);
+  for (size_t i = 0; i < pixel_count; i++) image_buffer[i] = Color(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+  const size_t rect = 32;
+  const size_t by = (H + rect - 1) / rect, bx = (W + rect - 1) / rect;
+  for (size_t index = 0; index < by * bx; index++) {
+    const size_t top = (index / bx) * rect, left = (index % bx) * rect;
+    const size_t h = std::min(rect, H - top), w = std::min(rect, W - left);
+    std::vector<Color> result(h * w);
+    for (size_t dy = 0; dy < h; dy++)
+      for (size_t dx = 0; dx < w; dx++) result[dy * w + dx] = image_buffer[(top + dy) * W + (left + dx)];
+    if (sender && !sender(Tile{{top, left}, {h, w}, std::move(result)})) {
+      std::printf("cancelled\n");  // mod.rs:110-113
+      return false;
+    }
+  }
+  return true;
+}
+
 void Camera::render(const Hittable& world, const TileSender& sender, const RenderTarget& target) const {
   if (target.world_size != 1)
     throw Error("Camera::render renders whole frames; use render_partial_sums + a reduce for multi-GPU");
   std::vector<float> sums = render_partial_sums(world, target);
-  const size_t pixel_count = image_width * image_height;
-  std::vector<double> rgb(pixel_count * 3);
-  check(target.ctx,
-        rt_resolve(target.ctx, sums.data(), (uint32_t)image_width, (uint32_t)image_height,
-                   (uint32_t)samples_per_pixel(), 2.2, rgb.data(), nullptr),
-        "rt_resolve");
-  std::vector<Color> image_buffer(pixel_count);
-  for (size_t i = 0; i < pixel_count; i++) image_buffer[i] = Color(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
-  // mod.rs:64-78,102-114: the same 32x32 tile tuples, in tile-index order
-  const size_t rect = 32;
-  const size_t by = (image_height + rect - 1) / rect, bx = (image_width + rect - 1) / rect;
-  for (size_t index = 0; index < by * bx; index++) {
-    const size_t top = (index / bx) * rect, left = (index % bx) * rect;
-    const size_t h = std::min(rect, image_height - top), w = std::min(rect, image_width - left);
-    std::vector<Color> result(h * w);
-    for (size_t dy = 0; dy < h; dy++)
-      for (size_t dx = 0; dx < w; dx++) result[dy * w + dx] = image_buffer[(top + dy) * image_width + (left + dx)];
-    if (sender && !sender(Tile{{top, left}, {h, w}, std::move(result)})) {
-      std::printf("cancelled\n");  // mod.rs:110-113
-      return;
+  std::vector<Color> image_buffer;
+  if (!send_tiles(*this, target.ctx, sums, samples_per_pixel(), sender, image_buffer)) return;
+  if (!target.ppm_path.empty()) write_buffer_to_file(target.ppm_path, image_buffer, image_width, image_height);
+}
+
+// ---- checkpoint file of render_progressive: header + W*H*3 f32 sums, little-endian, written to <path>.tmp and renamed
+namespace {
+struct CheckpointHeader {
+  char magic[8];  // "RTCKPT1\0"
+  uint64_t width, height, spp, passes, next_pass, seed, sampler_kind;
+};
+bool checkpoint_load(const std::string& path, const CheckpointHeader& want, CheckpointHeader& got, std::vector<float>& sums) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = std::fread(&got, sizeof(got), 1, f) == 1 && std::memcmp(got.magic, want.magic, 8) == 0 &&
+            got.width == want.width && got.height == want.height && got.spp == want.spp && got.passes == want.passes &&
+            got.seed == want.seed && got.sampler_kind == want.sampler_kind && got.next_pass <= got.passes;
+  if (ok) ok = std::fread(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+  std::fclose(f);
+  return ok;
+}
+void checkpoint_store(const std::string& path, const CheckpointHeader& h, const std::vector<float>& sums) {
+  const std::string tmp = path + ".tmp";
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) throw Error("cannot create " + tmp);
+  bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) throw Error("write failed: " + path);
+}
+}  // namespace
+
+size_t Camera::render_progressive(const Hittable& world, const TileSender& sender, const RenderTarget& target,
+                                  size_t passes, const std::string& checkpoint_path) const {
+  if (!target.ctx) throw Error("RenderTarget.ctx is null: the GPU backend is required (no CPU fallback)");
+  if (target.world_size != 1) throw Error("Camera::render_progressive renders whole frames on one GPU");
+  const size_t spp = samples_per_pixel();
+  if (passes == 0 || passes > spp) throw Error("render_progressive: passes must be in 1..samples_per_pixel");
+  FlatScene flat;
+  world.describe(flat);
+  rt_scene_desc desc = flat.desc();
+  SceneGuard g{target.ctx};
+  check(target.ctx, rt_scene_upload(target.ctx, &desc, &g.sc), "rt_scene_upload");
+  rt_camera cam = abi_camera();
+  const size_t n_val = image_width * image_height * 3;
+  std::vector<float> sums(n_val, 0.f), pass_sums(n_val);
+  CheckpointHeader hdr{};
+  std::memcpy(hdr.magic, "RTCKPT1", 8);
+  hdr.width = image_width; hdr.height = image_height; hdr.spp = spp; hdr.passes = passes; hdr.next_pass = 0;
+  hdr.seed = target.seed; hdr.sampler_kind = (uint64_t)cam.sampler_kind;
+  if (!checkpoint_path.empty()) {
+    CheckpointHeader got{};
+    std::vector<float> saved(n_val);
+    if (checkpoint_load(checkpoint_path, hdr, got, saved)) {
+      hdr.next_pass = got.next_pass;
+      sums.swap(saved);
     }
   }
+  std::vector<Color> image_buffer;
+  size_t rendered = 0;
+  for (size_t p = (size_t)hdr.next_pass; p < passes; p++) {
+    // pass p = sample indices {p, p + passes, ...} (Uniform: a sub-lattice of the n x n grid, so every pass
+    // already covers the pixel footprint evenly)
+    check(target.ctx,
+          rt_render(target.ctx, g.sc, &cam, target.seed, (uint32_t)p, (uint32_t)spp, (uint32_t)passes, pass_sums.data()),
+          "rt_render");
+    for (size_t i = 0; i < n_val; i++) sums[i] += pass_sums[i];
+    rendered++;
+    hdr.next_pass = p + 1;
+    if (!checkpoint_path.empty()) checkpoint_store(checkpoint_path, hdr, sums);
+    size_t done = 0;  // samples accumulated so far: |{s < spp : s % passes <= p}|
+    for (size_t q = 0; q <= p; q++) done += (spp - q + passes - 1) / passes;
+    if (!send_tiles(*this, target.ctx, sums, done, sender, image_buffer)) return rendered;
+  }
+  if (hdr.next_pass == passes && rendered == 0) {  // resumed a finished checkpoint: still deliver the frame
+    if (!send_tiles(*this, target.ctx, sums, spp, sender, image_buffer)) return rendered;
+  }
   if (!target.ppm_path.empty()) write_buffer_to_file(target.ppm_path, image_buffer, image_width, image_height);
+  return rendered;
 }
 
 void Camera::write_buffer_to_file(const std::string& path, const std::vector<Color>& image_buffer, size_t width,

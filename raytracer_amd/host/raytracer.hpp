@@ -368,6 +368,15 @@ class Camera {  // mod.rs:26-51
   void render(const Hittable& world, const TileSender& sender, const RenderTarget& target) const;
   // un-normalised linear sums of this rank's sample subset (for an external multi-GPU reduce)
   std::vector<float> render_partial_sums(const Hittable& world, const RenderTarget& target) const;
+  // Progressive form of render() for the live preview (the reference streams tiles to ui.rs:56-77 as they
+  // finish; a GPU frame finishes all tiles at once, so the preview is refreshed per PASS instead): the samples
+  // are split into `passes` residue classes, and after each pass every tile is sent with the mean of the samples
+  // rendered so far (same tuples as render()).  A hang-up prints "cancelled" and returns.  When
+  // `checkpoint_path` is non-empty the accumulated sums are written there after every pass (atomically) and a
+  // matching checkpoint found at start is resumed — the 10 000-spp runs of C5 survive a restart.  The final
+  // frame equals render()'s up to f32 summation order (counter-based sample keys).  Returns passes rendered now.
+  size_t render_progressive(const Hittable& world, const TileSender& sender, const RenderTarget& target, size_t passes,
+                            const std::string& checkpoint_path = "") const;
   rt_camera abi_camera() const;
   size_t samples_per_pixel() const;
   PixelSampler pixel_sampler{PixelSamplerKind::Uniform, 1};

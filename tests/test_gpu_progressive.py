@@ -1,0 +1,87 @@
+"""GPU tests of the progressive / checkpointed form of Camera::render: per-pass tile
+refresh for the preview channel (ui.rs:56-77 consumes the same tuples), checkpoint + resume of the accumulated
+sums, and equality of the final frame with the single-shot render."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+
+pytestmark = pytest.mark.gpu
+ASPECT = 16.0 / 9.0
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ra.Context(0)
+    yield c
+    c.close()
+
+
+def test_progressive_final_frame_equals_single_shot(ctx, tmp_path):
+    g = ra.Scene("book_cover", 80, ASPECT, "uniform", 16, 8)
+    ref, tiles = g.render(ctx, seed=3)
+    ppm = tmp_path / "image.ppm"
+    frame, rendered, n_msgs = g.render_progressive(ctx, passes=4, seed=3, ppm_path=str(ppm))
+    assert rendered == 4 and n_msgs == 4 * len(tiles)  # every tile re-sent after every pass
+    # counter-based sample keys: the partition into passes changes only the f32 summation order
+    assert np.allclose(frame, ref, rtol=0, atol=2e-6)
+    assert ppm.read_text().split("\n")[1] == "80 45"
+    # passes need not divide the sample count; the random sampler works too
+    g2 = ra.Scene("two_spheres", 64, ASPECT, "random", 10, 8)
+    ref2, _ = g2.render(ctx, seed=5)
+    frame2, rendered2, _ = g2.render_progressive(ctx, passes=3, seed=5)
+    assert rendered2 == 3 and np.allclose(frame2, ref2, rtol=0, atol=2e-6)
+
+
+def test_progressive_preview_converges_pass_by_pass(ctx):
+    g = ra.Scene("book_cover", 64, ASPECT, "uniform", 64, 8)
+    ref, tiles = g.render(ctx, seed=9)
+    snaps, cur = [], np.zeros_like(ref)
+    state = {"n": 0}
+
+    def on_tile(top, left, h, w, rgb):
+        cur[top:top + h, left:left + w] = rgb
+        state["n"] += 1
+        if state["n"] % len(tiles) == 0:
+            snaps.append(cur.copy())
+
+    g.render_progressive(ctx, passes=8, seed=9, on_tile=on_tile)
+    assert len(snaps) == 8
+    err = [float(np.sqrt(np.mean((s - ref) ** 2))) for s in snaps]
+    assert err[-1] < 2e-6 and err[0] > 4 * err[-2] > 0  # 8 spp preview is noisy, 56 spp is close
+
+
+def test_checkpoint_resume_after_cancel(ctx, tmp_path):
+    g = ra.Scene("book_cover", 80, ASPECT, "uniform", 16, 8)
+    ref, tiles = g.render(ctx, seed=11)
+    ck = str(tmp_path / "render.ckpt")
+    state = {"n": 0}
+
+    def hang_up_in_third_pass(*_a):
+        state["n"] += 1
+        return state["n"] <= 2 * len(tiles)  # False on the first tile of pass 3
+
+    ppm = tmp_path / "image.ppm"
+    _, rendered, _ = g.render_progressive(ctx, passes=4, seed=11, checkpoint_path=ck, ppm_path=str(ppm),
+                                          on_tile=hang_up_in_third_pass)
+    assert rendered == 3 and not ppm.exists() and os.path.exists(ck)  # pass 3 was rendered + saved, then cancelled
+    assert os.path.getsize(ck) == 64 + 80 * 45 * 3 * 4 and not os.path.exists(ck + ".tmp")
+    frame, rendered, n_msgs = g.render_progressive(ctx, passes=4, seed=11, checkpoint_path=ck, ppm_path=str(ppm))
+    assert rendered == 1 and n_msgs == len(tiles) and ppm.exists()  # only the missing pass is rendered
+    assert np.allclose(frame, ref, rtol=0, atol=2e-6)
+    # a finished checkpoint renders nothing more but still delivers the frame
+    frame, rendered, n_msgs = g.render_progressive(ctx, passes=4, seed=11, checkpoint_path=ck)
+    assert rendered == 0 and n_msgs == len(tiles) and np.allclose(frame, ref, rtol=0, atol=2e-6)
+    # a checkpoint of another job (different seed) is ignored, not resumed
+    frame, rendered, _ = g.render_progressive(ctx, passes=4, seed=12, checkpoint_path=ck)
+    assert rendered == 4 and not np.allclose(frame, ref, atol=1e-3)
+
+
+def test_progressive_argument_errors(ctx):
+    g = ra.Scene("two_spheres", 32, ASPECT, "uniform", 4, 4)
+    with pytest.raises(RuntimeError, match="passes must be in 1"):
+        g.render_progressive(ctx, passes=5)
+    with pytest.raises(RuntimeError, match="passes must be in 1"):
+        g.render_progressive(ctx, passes=0)
