@@ -255,88 +255,114 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedP
 
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long my_rays = 0;
+  // ---- wave state.  The wave works on one unit (8x8 tile x Ku sample indices) at a time; when the unit's sample pool
+  // is exhausted it moves on to the next unit AT ONCE: the tile's LDS accumulators are flushed, the paths still in
+  // flight become "stragglers" that add their radiance straight to the global frame, and the freed lanes are fed
+  // from the new unit.  Lanes therefore never idle through a unit's drain (up to max_depth bounces of its
+  // longest path) — only through the last one of the wave.
+  uint32_t x0 = 0, y0 = 0, k_lo = 0, total = 0, next = 0;  // wave-uniform: current unit and its pool cursor
+  bool have_unit = false, exhausted = false;               // wave-uniform
+  bool active = false, straggler = false;
+  d3 o = {0, 0, 0}, d = {0, 0, 0};
+  double time = 0;
+  f3 thr = {1.f, 1.f, 1.f};
+  uint32_t depth = 0, lpix = 0;  // lpix: pixel index inside the tile, or (straggler) 3 * global pixel index
+  PathRng rng = {0, 0};
+  l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
+  __builtin_amdgcn_wave_barrier();
+  // shade one finished traversal; returns true when the path continues with a new ray in (o, d)
+  auto bounce = [&](HitInfo hit) -> bool {
+    if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
+    ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
+    if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
+    if (!so.alive) {
+      const unsigned long long r = to_fix(so.radiance.x), g = to_fix(so.radiance.y), b = to_fix(so.radiance.z);
+      if (straggler) {
+        if (r) atomicAdd(&fbacc[lpix + 0], r);
+        if (g) atomicAdd(&fbacc[lpix + 1], g);
+        if (b) atomicAdd(&fbacc[lpix + 2], b);
+      } else {
+        atomicAdd(&l_acc[lpix * 3 + 0], r);
+        atomicAdd(&l_acc[lpix * 3 + 1], g);
+        atomicAdd(&l_acc[lpix * 3 + 2], b);
+      }
+      return false;
+    }
+    depth++;
+    if (depth >= cam.max_depth) return false;  // mod.rs:195-197: black
+    o = so.o; d = so.d; thr = so.thr;
+    return true;
+  };
   while (true) {
-    uint32_t u = 0;
-    if (lane == 0) u = atomicAdd(unit_counter, 1u);
-    u = __shfl(u, 0, 64);
-    if (u >= fp.n_units) break;
-    const uint32_t tile = u % fp.n_tiles, chunk = u / fp.n_tiles;
-    const uint32_t x0 = (tile % fp.tiles_x) * 8, y0 = (tile / fp.tiles_x) * 8;
-    const uint32_t k_lo = chunk * fp.Ku;
-    const uint32_t k_n = min(fp.Ku, fp.K - k_lo);
-    const uint32_t total = 64u * k_n;
-    l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t next = 0;  // wave-uniform pool cursor
-    bool active = false;
-    d3 o = {0, 0, 0}, d = {0, 0, 0};
-    double time = 0;
-    f3 thr = {1.f, 1.f, 1.f};
-    uint32_t depth = 0, lpix = 0;
-    PathRng rng = {0, 0};
-    // shade one finished traversal; returns true when the path continues with a new ray in (o, d)
-    auto bounce = [&](HitInfo hit) -> bool {
-      if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
-      ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
-      if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
-      if (!so.alive) {
-        atomicAdd(&l_acc[lpix * 3 + 0], to_fix(so.radiance.x));
-        atomicAdd(&l_acc[lpix * 3 + 1], to_fix(so.radiance.y));
-        atomicAdd(&l_acc[lpix * 3 + 2], to_fix(so.radiance.z));
-        return false;
-      }
-      depth++;
-      if (depth >= cam.max_depth) return false;  // mod.rs:195-197: black
-      o = so.o; d = so.d; thr = so.thr;
-      return true;
-    };
-    while (true) {
-      // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
-      unsigned long long need = __ballot(!active);
-      if (STATS) st_t0 = now_cycles();
-      if (need && next < total) {
-        uint32_t j = next + wave_prefix(need);
-        if (!active && j < total) {
-          uint32_t pit = j & 63u, ks = j >> 6;
-          uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
-          if (px < cam.width && py < cam.height) {
-            if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
-            uint32_t pixel = py * cam.width + px;
-            uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
-            generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
-            thr = {1.f, 1.f, 1.f};
-            depth = 0;
-            lpix = pit;
-            active = true;
-          }
+    // ---- next unit when the pool is empty
+    if (next >= total && !exhausted) {
+      if (have_unit) {  // flush the finished tile's accumulators; paths still in flight go on as stragglers
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
+        if (px < cam.width && py < cam.height) {
+          const size_t p = ((size_t)py * cam.width + px) * 3;
+          const unsigned long long a0 = l_acc[lane * 3], a1 = l_acc[lane * 3 + 1], a2 = l_acc[lane * 3 + 2];
+          if (a0) atomicAdd(&fbacc[p], a0);
+          if (a1) atomicAdd(&fbacc[p + 1], a1);
+          if (a2) atomicAdd(&fbacc[p + 2], a2);
         }
-        next = min(total, next + (uint32_t)__popcll(need));
+        l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (active && !straggler) {
+          straggler = true;
+          lpix = ((y0 + (lpix >> 3)) * cam.width + x0 + (lpix & 7u)) * 3u;
+        }
       }
-      if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
-      if (__ballot(active) == 0ull) {
-        if (next >= total) break;
-        continue;
-      }
-      if (active) {
-        // ---- one bounce for every lane that carries a path: closest hit, then shade
-        my_rays++;
-        HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
-                                                                          stack, BLOCK, &tc, rng);
-        if (!bounce(hit)) active = false;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    {  // flush the tile's accumulators
-      uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
-      if (px < cam.width && py < cam.height) {
-        size_t p = ((size_t)py * cam.width + px) * 3;
-        unsigned long long a0 = l_acc[lane * 3], a1 = l_acc[lane * 3 + 1], a2 = l_acc[lane * 3 + 2];
-        if (a0) atomicAdd(&fbacc[p], a0);
-        if (a1) atomicAdd(&fbacc[p + 1], a1);
-        if (a2) atomicAdd(&fbacc[p + 2], a2);
+      uint32_t u = 0;
+      if (lane == 0) u = atomicAdd(unit_counter, 1u);
+      u = __shfl(u, 0, 64);
+      if (u >= fp.n_units) {
+        exhausted = true;
+        have_unit = false;
+        total = 0; next = 0;
+      } else {
+        const uint32_t tile = u % fp.n_tiles, chunk = u / fp.n_tiles;
+        x0 = (tile % fp.tiles_x) * 8; y0 = (tile / fp.tiles_x) * 8;
+        k_lo = chunk * fp.Ku;
+        total = 64u * min(fp.Ku, fp.K - k_lo);
+        next = 0;
+        have_unit = true;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
+    unsigned long long need = __ballot(!active);
+    if (STATS) st_t0 = now_cycles();
+    if (need && next < total) {
+      uint32_t j = next + wave_prefix(need);
+      if (!active && j < total) {
+        uint32_t pit = j & 63u, ks = j >> 6;
+        uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
+        if (px < cam.width && py < cam.height) {
+          if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
+          uint32_t pixel = py * cam.width + px;
+          uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
+          generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
+          thr = {1.f, 1.f, 1.f};
+          depth = 0;
+          lpix = pit;
+          straggler = false;
+          active = true;
+        }
+      }
+      next = min(total, next + (uint32_t)__popcll(need));
+    }
+    if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
+    if (__ballot(active) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+    if (active) {
+      // ---- one bounce for every lane that carries a path: closest hit, then shade
+      my_rays++;
+      HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
+                                                                        stack, BLOCK, &tc, rng);
+      if (!bounce(hit)) active = false;
+    }
   }
   // rays traced (stats): one atomic per wave
   for (int off2 = 32; off2 > 0; off2 >>= 1) my_rays += __shfl_down(my_rays, off2, 64);
@@ -1054,12 +1080,13 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   if (per_cu < 1) return fail(ctx, RT_E_INTERNAL, "fused kernel does not fit on a CU");
   const uint32_t waves = (uint32_t)ctx->n_cu * (uint32_t)per_cu * (BLOCK / 64);
   FusedParams fp = fp0;
-  // work-unit size: ~24 units per resident wave for load balance, unless overridden
+  // work-unit size: ~48 units per resident wave for load balance at the end of the frame (a wave switches units
+  // without draining, so small units cost only their flush), unless overridden
   uint32_t chunks = 1;
   if (ctx->fused_ku > 0) {
     chunks = (fp.K + (uint32_t)ctx->fused_ku - 1) / (uint32_t)ctx->fused_ku;
   } else {
-    uint64_t target = (uint64_t)waves * 24;
+    uint64_t target = (uint64_t)waves * 48;
     chunks = (uint32_t)std::min<uint64_t>(fp.K, std::max<uint64_t>(1, target / fp.n_tiles));
   }
   fp.Ku = (fp.K + chunks - 1) / chunks;

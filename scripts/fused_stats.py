@@ -42,3 +42,6 @@ if "--occ" in sys.argv:
     ctx.set_option("fused_lds", 1)
 if "--stats" in sys.argv:
     run(True)
+if "--ku" in sys.argv:  # work-unit size (samples of one 8x8 tile per unit)
+    for ku in (0, 2, 4, 7, 10, 13, 20, 25, 34, 50, 100):
+        run(False, fused_ku=ku)
