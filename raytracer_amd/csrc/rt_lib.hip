@@ -1150,7 +1150,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     if (scene->spheres_only && lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
     else if (scene->spheres_only) rc = launch_fused<RT_F_TEX_ANY, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
     else if (tex_only == 0) rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else if (ctx->fused_stats) {
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
+      rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t, true>(ctx, scene, dc, fp, smem, st);
+    } else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
   }
   if (rc) return rc;
   tm.end(ctx->stats.ms_intersect);

@@ -7,7 +7,14 @@ import raytracer_amd as ra
 ctx = ra.Context(0)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 spp = int(args[0]) if args else 100
-sc = ra.Scene("book_cover", 1200, 16 / 9, "uniform", spp, 50)
+scene_name = next((a.split("=")[1] for a in sys.argv if a.startswith("--scene=")), "book_cover")
+width = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--width=")), 1200))
+texels = None
+if scene_name in ("earth", "final_scene", "final_scene_small"):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from golden_data import load_earth_rgba
+    texels = load_earth_rgba()
+sc = ra.Scene(scene_name, width, 16 / 9, "uniform", spp, 50, texels=texels)
 dev = sc.upload(ctx)
 cam = sc.camera_copy()
 
