@@ -156,10 +156,12 @@ __device__ __forceinline__ f3 normalize(f3 a) {
 // Per-ray constants of the f32 slab test.  t = plane*inv - (o*inv); the origin's f32 rounding error
 // |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
 // coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
+#define RT_SLAB_WIDEN 1.0000019f  // exit distances are widened by 16 ulp (+1e-30) before the entry <= exit test
 struct SlabRay {
-  float ix, iy, iz;
-  float nx, ny, nz;
-  float fx, fy, fz;
+  float ix, iy, iz;     // 1/d
+  float nx, ny, nz;     // o/d widened towards later entry ... subtracted from plane/d for entry planes
+  float ixw, iyw, izw;  // (1/d) * RT_SLAB_WIDEN: exit planes carry the widening factor in their multiplier
+  float fx, fy, fz;     // (o/d widened towards earlier exit) * RT_SLAB_WIDEN - 1e-30
   bool sx, sy, sz;       // direction negative on axis (select-based node fetch: GlobalAcc / SphereAcc)
   uint32_t ox, oy, oz;   // byte offset of the ray's direction-ordered plane quad inside a slab node (SlabLdsAcc)
 };
@@ -175,28 +177,32 @@ __device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
   const float E = 9.5367431640625e-07f;  // 2^-20: > 8 ulp, covers o / d / rcp / fma rounding
   float ex = __builtin_fabsf(ax) * E, ey = __builtin_fabsf(ay) * E, ez = __builtin_fabsf(az) * E;
   s.nx = ax + ex; s.ny = ay + ey; s.nz = az + ez;
-  s.fx = ax - ex; s.fy = ay - ey; s.fz = az - ez;
+  s.ixw = s.ix * RT_SLAB_WIDEN; s.iyw = s.iy * RT_SLAB_WIDEN; s.izw = s.iz * RT_SLAB_WIDEN;
+  s.fx = (ax - ex) * RT_SLAB_WIDEN - 1e-30f; s.fy = (ay - ey) * RT_SLAB_WIDEN - 1e-30f;
+  s.fz = (az - ez) * RT_SLAB_WIDEN - 1e-30f;
   s.sx = s.ix < 0.f; s.sy = s.iy < 0.f; s.sz = s.iz < 0.f;
   s.ox = s.sx ? 16u : 0u; s.oy = s.sy ? 48u : 32u; s.oz = s.sz ? 80u : 64u;
   return s;
 }
 // Both children of a node at once.  Each axis quad holds (entry L, entry R, exit L, exit R): the children's planes
-// already ordered for the ray's direction.  tl / tr: entry distances clamped to 0; hit iff entry <= exit
-// (widened).  fmaxf/fminf ignore NaN (0*inf axes) => conservative.
-__device__ __forceinline__ void slab_pair_test(const SlabRay& s, float4 qx, float4 qy, float4 qz, float tmax, float& tl,
+// already ordered for the ray's direction.  tl / tr: entry distances clamped to 0; hit iff entry <= widened exit.
+// The widening (x RT_SLAB_WIDEN + 1e-30) is folded into the exit planes' per-ray constants and into `tmax_w`
+// (= tmax * RT_SLAB_WIDEN + 1e-30, kept by the caller): min(a, b) * K + c == min(a * K + c, b * K + c) for K > 0.
+// fmaxf/fminf ignore NaN (0*inf axes) => conservative.
+__device__ __forceinline__ void slab_pair_test(const SlabRay& s, float4 qx, float4 qy, float4 qz, float tmax_w, float& tl,
                                                float& tr, bool& hl, bool& hr) {
   const float t0xl = __builtin_fmaf(qx.x, s.ix, -s.nx), t0xr = __builtin_fmaf(qx.y, s.ix, -s.nx);
-  const float t1xl = __builtin_fmaf(qx.z, s.ix, -s.fx), t1xr = __builtin_fmaf(qx.w, s.ix, -s.fx);
+  const float t1xl = __builtin_fmaf(qx.z, s.ixw, -s.fx), t1xr = __builtin_fmaf(qx.w, s.ixw, -s.fx);
   const float t0yl = __builtin_fmaf(qy.x, s.iy, -s.ny), t0yr = __builtin_fmaf(qy.y, s.iy, -s.ny);
-  const float t1yl = __builtin_fmaf(qy.z, s.iy, -s.fy), t1yr = __builtin_fmaf(qy.w, s.iy, -s.fy);
+  const float t1yl = __builtin_fmaf(qy.z, s.iyw, -s.fy), t1yr = __builtin_fmaf(qy.w, s.iyw, -s.fy);
   const float t0zl = __builtin_fmaf(qz.x, s.iz, -s.nz), t0zr = __builtin_fmaf(qz.y, s.iz, -s.nz);
-  const float t1zl = __builtin_fmaf(qz.z, s.iz, -s.fz), t1zr = __builtin_fmaf(qz.w, s.iz, -s.fz);
+  const float t1zl = __builtin_fmaf(qz.z, s.izw, -s.fz), t1zr = __builtin_fmaf(qz.w, s.izw, -s.fz);
   tl = fmaxf(fmaxf(fmaxf(t0xl, t0yl), t0zl), 0.f);
   tr = fmaxf(fmaxf(fmaxf(t0xr, t0yr), t0zr), 0.f);
-  const float fl = fminf(fminf(fminf(t1xl, t1yl), t1zl), tmax);
-  const float fr = fminf(fminf(fminf(t1xr, t1yr), t1zr), tmax);
-  hl = tl <= fl * 1.0000019f + 1e-30f;
-  hr = tr <= fr * 1.0000019f + 1e-30f;
+  const float fl = fminf(fminf(fminf(t1xl, t1yl), t1zl), tmax_w);
+  const float fr = fminf(fminf(fminf(t1xr, t1yr), t1zr), tmax_w);
+  hl = tl <= fl;
+  hr = tr <= fr;
 }
 // 64-B node (l_lo l_hi r_lo r_hi as three float4) -> direction-ordered plane quads by select
 __device__ __forceinline__ void slab_select(const SlabRay& s, float4 q0, float4 q1, float4 q2, float4& qx, float4& qy,
@@ -441,7 +447,7 @@ struct TravState {
   int32_t sp;   // entries on the stack, INCLUDING the one cached in `top`
   int32_t top;  // top-of-stack kept in a register: a pop never waits on LDS (its refill load overlaps the next step)
   int32_t best_prim;
-  float tmax32;
+  float tmax_w;  // f32 upper bound of best_t, widened: ru(best_t) * RT_SLAB_WIDEN + 1e-30
   double best_t;
   double a, inv_a;  // |d|^2 (geometry.rs:43) and its reciprocal
   SlabRay s;
@@ -459,7 +465,7 @@ __device__ __forceinline__ void trav_init(TravState& ts, int32_t root, d3 o, d3 
   ts.top = RT_DONE;
   ts.best_prim = -1;
   ts.best_t = __builtin_inf();
-  ts.tmax32 = __builtin_inff();
+  ts.tmax_w = __builtin_inff();
   ts.a = d.x * d.x + d.y * d.y + d.z * d.z;
   ts.inv_a = fast_rcp(ts.a);
   ts.s = make_slab(o, d);
@@ -487,7 +493,7 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
   acc.node_slabs(ts.cur, ts.s, qx, qy, qz, ch);
   float tl, tr;
   bool hl, hr;
-  slab_pair_test(ts.s, qx, qy, qz, ts.tmax32, tl, tr, hl, hr);
+  slab_pair_test(ts.s, qx, qy, qz, ts.tmax_w, tl, tr, hl, hr);
   const bool left_first = tl <= tr;
   const bool take_left = hl && (!hr || left_first);
   if (hl && hr) trav_push(ts, left_first ? ch.y : ch.x, stack, stride);
@@ -518,7 +524,7 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
   if (h) {
     ts.best_t = t;
     ts.best_prim = pi;
-    ts.tmax32 = __double2float_ru(t);
+    ts.tmax_w = __double2float_ru(t) * RT_SLAB_WIDEN + 1e-30f;
   }
   trav_pop(ts, stack, stride);
 }
