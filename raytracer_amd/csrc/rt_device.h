@@ -459,16 +459,24 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, d3 o, d3 d) {
+// the part of the state that is a function of the ray alone (recomputed rather than kept across shading)
+__device__ __forceinline__ void trav_ray_constants(TravState& ts, d3 o, d3 d) {
+  ts.a = d.x * d.x + d.y * d.y + d.z * d.z;
+  ts.inv_a = fast_rcp(ts.a);
+  ts.s = make_slab(o, d);
+}
+// the part that records progress: current node, stack, best hit so far
+__device__ __forceinline__ void trav_restart(TravState& ts, int32_t root) {
   ts.cur = root;
   ts.sp = 0;
   ts.top = RT_DONE;
   ts.best_prim = -1;
   ts.best_t = __builtin_inf();
   ts.tmax_w = __builtin_inff();
-  ts.a = d.x * d.x + d.y * d.y + d.z * d.z;
-  ts.inv_a = fast_rcp(ts.a);
-  ts.s = make_slab(o, d);
+}
+__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, d3 o, d3 d) {
+  trav_restart(ts, root);
+  trav_ray_constants(ts, o, d);
 }
 template <class StackT>
 __device__ __forceinline__ void trav_push(TravState& ts, int32_t v, StackT* stack, int stride) {
@@ -557,6 +565,39 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
   best.t = ts.best_t;
   best.prim = ts.best_prim;
   return best;
+}
+
+// Resumable form of traverse() for a wave whose lanes carry independent traversals (k_fused, RESUME variant).
+// Advances the participating lanes' traversals and hands the wave back once fewer than `min_busy` of them are
+// unfinished (min_busy = 1: run everything to completion).  Inside, the inner-node loop is left as soon as fewer
+// than `kn` lanes still walk inner nodes while some lane waits at a leaf (kn = 1: plain while-while).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+template <class Acc, class StackT, bool COUNT>
+__device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, bool participating, uint32_t features,
+                                                d3 o, d3 d, double time, double tmin, StackT* stack, int stride,
+                                                TravCounters* cnt, PathRng& rng, uint32_t min_busy, uint32_t kn) {
+  while (true) {
+    const bool busy = participating && ts.cur != RT_DONE;
+    const unsigned long long m_busy = wave_ballot(busy);
+    if ((uint32_t)__popcll(m_busy) < min_busy) break;
+    unsigned long long m_node = wave_ballot(ts.cur >= 0) & m_busy;
+    const uint32_t need = (m_node != m_busy) ? kn : 1u;
+    uint64_t t0 = 0;
+    if (COUNT) t0 = now_cycles();
+    while ((uint32_t)__popcll(m_node) >= need) {
+      if (busy && ts.cur >= 0) {
+        if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
+        node_step(acc, ts, stack, stride);
+      }
+      m_node = wave_ballot(ts.cur >= 0) & m_busy;
+    }
+    if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
+    if (busy && ts.cur < 0 && ts.cur != RT_DONE) {
+      if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
+      leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
+      if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
+    }
+  }
 }
 
 // Full hit record of (prim, t) — geometry.rs:58-70.

@@ -192,6 +192,8 @@ struct FusedParams {
   uint32_t tiles_x, n_tiles, n_units;
   uint32_t k0, k1;
   uint32_t stack_depth;
+  uint32_t kb, kn;  // RESUME variant: hand-back / node-loop exit thresholds (traverse_resume)
+  uint32_t kr;      // regenerate only when at least kr lanes are free (or none carries a path)
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
 
@@ -223,7 +225,7 @@ template <> struct AccOf<KIND_GENERIC> {
   static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return global_acc(sc); }
 };
 
-template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
 __global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
                                                  unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
@@ -270,6 +272,13 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedP
   PathRng rng = {0, 0};
   l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
   __builtin_amdgcn_wave_barrier();
+  // RESUME: the lane's traversal progress (node, stack, best hit) survives shade / regenerate rounds of its
+  // neighbours; the per-ray constants are recomputed each round (unconditionally, so that they are not live across
+  // the shading code)
+  int32_t t_cur = RT_DONE, t_sp = 0, t_top = RT_DONE, t_best_prim = -1;
+  double t_best_t = 0;
+  bool fresh_lane = false;  // this lane holds a ray whose traversal has not started
+  bool fresh = false;       // wave-uniform: some lane received a new ray since the last traversal call
   // shade one finished traversal; returns true when the path continues with a new ray in (o, d)
   auto bounce = [&](HitInfo hit) -> bool {
     if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
@@ -332,7 +341,8 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedP
     // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
     unsigned long long need = __ballot(!active);
     if (STATS) st_t0 = now_cycles();
-    if (need && next < total) {
+    const uint32_t n_free = (uint32_t)__popcll(need);
+    if (n_free && (n_free >= fp.kr || n_free == 64u) && next < total) {
       uint32_t j = next + wave_prefix(need);
       if (!active && j < total) {
         uint32_t pit = j & 63u, ks = j >> 6;
@@ -347,16 +357,39 @@ __global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedP
           lpix = pit;
           straggler = false;
           active = true;
+          fresh_lane = true;
         }
       }
       next = min(total, next + (uint32_t)__popcll(need));
+      fresh = true;
     }
     if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
     if (__ballot(active) == 0ull) {
       if (exhausted) break;
       continue;
     }
-    if (active) {
+    if (RESUME) {
+      TravState ts;
+      trav_ray_constants(ts, o, d);  // all lanes (garbage in lanes without a path is never used)
+      if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = 0; t_top = RT_DONE; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
+      fresh_lane = false;
+      ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
+      ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
+      // ---- traverse until fewer than kb lanes are unfinished (stragglers keep their progress and go on next round
+      //      beside the re-launched lanes); when nothing new was launched, run to completion
+      traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
+                                                                 &tc, rng, fresh ? fp.kb : 1u, fp.kn);
+      t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
+      const bool ready = active && t_cur == RT_DONE;
+      fresh = __ballot(ready) != 0ull;
+      if (ready) {
+        HitInfo hit;
+        hit.t = t_best_t;
+        hit.prim = t_best_prim;
+        if (bounce(hit)) fresh_lane = true;
+        else active = false;
+      }
+    } else if (active) {
       // ---- one bounce for every lane that carries a path: closest hit, then shade
       my_rays++;
       HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
@@ -469,7 +502,8 @@ struct rt_ctx {
   int fused_ku = 0;          // samples per work unit (0 = auto)
   int fused_lds = 1;         // keep the scene in LDS when it fits
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
-  int fused_block = 1024;    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
+  int fused_kr = 16;
+  int fused_resume = 2, fused_kb = 16, fused_kn = 8;  // 0 bounce-synchronous, 1 resumable traversals, 2 by scene size  // RESUME variant of k_fused + its thresholds    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
   float* d_dbg = nullptr;
   WorkBuffers wb;
   uint32_t* d_unit_counter = nullptr;
@@ -629,9 +663,12 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_lds = value ? 1 : 0;
   } else if (k == "fused_stats") {
     ctx->fused_stats = value ? 1 : 0;
-  } else if (k == "fused_block") {
-    if (value != 1024 && value != 512 && value != 256) return fail(ctx, RT_E_INVALID_ARG, "fused_block must be 1024, 512 or 256");
-    ctx->fused_block = (int)value;
+  } else if (k == "fused_resume") {
+    if (value < 0 || value > 2) return fail(ctx, RT_E_INVALID_ARG, "fused_resume must be 0, 1 or 2");
+    ctx->fused_resume = (int)value;
+  } else if (k == "fused_kb" || k == "fused_kn" || k == "fused_kr") {
+    if (value < 1 || value > 64) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 1..64");
+    (k == "fused_kb" ? ctx->fused_kb : k == "fused_kn" ? ctx->fused_kn : ctx->fused_kr) = (int)value;
   } else {
     return fail(ctx, RT_E_INVALID_ARG, "rt_set_option: unknown key " + k);
   }
@@ -1069,10 +1106,10 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 }
 
 // ---- fused mode: one persistent kernel, no path state in HBM
-template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false>
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
-  auto kern = k_fused<F, KIND, BLOCK, StackT, STATS>;
+  auto kern = k_fused<F, KIND, BLOCK, StackT, STATS, RESUME>;
   HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
   int per_cu = 0;
@@ -1099,6 +1136,20 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   return RT_OK;
 }
 
+// Resumable traversals pay when rays of one wave need very different numbers of BVH steps — i.e. when there is a
+// tree to speak of.  On one- or two-object scenes (C3) every traversal is a couple of steps and the plain
+// bounce-synchronous loop is 15-20 % faster; from a few dozen primitives on (C1/C2, C5) the resumable form wins.
+static bool use_resume(const rt_ctx* ctx, const rt_scene* scene) {
+  return ctx->fused_resume == 1 || (ctx->fused_resume == 2 && scene->view.n_prims >= 32);
+}
+// production instances: the traversal schedule (RESUME or bounce-synchronous) is a run-time choice
+template <uint32_t F, int KIND, int BLOCK, class StackT>
+static int launch_variant(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp, size_t smem,
+                          hipStream_t st) {
+  if (use_resume(ctx, scene)) return launch_fused<F, KIND, BLOCK, StackT, false, true>(ctx, scene, dc, fp, smem, st);
+  return launch_fused<F, KIND, BLOCK, StackT, false, false>(ctx, scene, dc, fp, smem, st);
+}
+
 static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const Camera& dc, uint64_t seed,
                         uint32_t sample_begin, uint32_t sample_stride, uint32_t K, float* d_out_sum, hipStream_t st) {
   const size_t n_val = (size_t)cam->width * cam->height * 3;
@@ -1120,6 +1171,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
+  fp.kb = (uint32_t)ctx->fused_kb; fp.kn = (uint32_t)ctx->fused_kn; fp.kr = use_resume(ctx, scene) ? (uint32_t)ctx->fused_kr : 1u;
   const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
   const uint32_t tex_only = scene->features & RT_F_TEX_ANY;  // texture kinds present (kernels are specialised on them)
   const bool small_ids = (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768 && scene->view.n_prims < 32000;  // int16 stack entries
@@ -1131,29 +1183,26 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
                                   16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   StageTimer tm(ctx, st);
   tm.begin();
+  if (ctx->fused_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
     if (lean && ctx->fused_stats) {
-      HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
-      rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true>(ctx, scene, dc, fp, lds_1024, st);
-    } else if (lean && ctx->fused_block == 512) {
-      rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 512, int16_t>(ctx, scene, dc, fp, lds_scene + 8 * 192 * 8 + (size_t)sdepth * 512 * 2, st);
-    } else if (lean && ctx->fused_block == 256) {
-      rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 256, int16_t>(ctx, scene, dc, fp, lds_scene + 4 * 192 * 8 + (size_t)sdepth * 256 * 2, st);
-    } else if (lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
-    else if (tex_only == RT_F_TEX_IMAGE) rc = launch_fused<RT_F_TEX_IMAGE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
-    else rc = launch_fused<RT_F_TEX_ANY, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+      if (use_resume(ctx, scene)) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true, true>(ctx, scene, dc, fp, lds_1024, st);
+      else rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true, false>(ctx, scene, dc, fp, lds_1024, st);
+    } else if (lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else if (tex_only == RT_F_TEX_IMAGE) rc = launch_variant<RT_F_TEX_IMAGE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
   } else if (!scene->spheres_only && ctx->fused_lds && small_ids && lds_generic_1024 <= 160 * 1024) {
-    if (tex_only == 0) rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
-    else rc = launch_fused<RT_F_ALL, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
+    if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
+    else rc = launch_variant<RT_F_ALL, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
   } else {
     const size_t smem = 4 * 192 * 8 + (size_t)sdepth * 256 * 4;
-    if (scene->spheres_only && lean) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else if (scene->spheres_only) rc = launch_fused<RT_F_TEX_ANY, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else if (tex_only == 0) rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    else if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
     else if (ctx->fused_stats) {
-      HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
-      rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t, true>(ctx, scene, dc, fp, smem, st);
-    } else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+      if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t, true, true>(ctx, scene, dc, fp, smem, st);
+      else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t, true, false>(ctx, scene, dc, fp, smem, st);
+    } else rc = launch_variant<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
   }
   if (rc) return rc;
   tm.end(ctx->stats.ms_intersect);

@@ -43,12 +43,35 @@ def run(stats, **opts):
 
 run(False)
 if "--occ" in sys.argv:
-    run(False, fused_block=512)
-    run(False, fused_block=256)
-    run(False, fused_block=1024, fused_lds=0)
+    run(False, fused_lds=0)
     ctx.set_option("fused_lds", 1)
 if "--stats" in sys.argv:
     run(True)
 if "--ku" in sys.argv:  # work-unit size (samples of one 8x8 tile per unit)
     for ku in (0, 2, 4, 7, 10, 13, 20, 25, 34, 50, 100):
         run(False, fused_ku=ku)
+if "--resume" in sys.argv:  # RESUME variant of k_fused: hand-back (kb) and node-loop exit (kn) thresholds
+    for kb, kn in ((1, 1), (16, 1), (8, 8), (16, 8), (24, 8), (16, 4), (12, 4), (16, 12), (24, 16), (32, 16)):
+        run(False, fused_resume=1, fused_kb=kb, fused_kn=kn)
+    run(True, fused_resume=1, fused_kb=16, fused_kn=8)
+    run(False, fused_resume=0)
+if "--kr" in sys.argv:
+    for res, kr in ((0, 1), (0, 4), (0, 8), (0, 16), (1, 1), (1, 4), (1, 8), (1, 12), (1, 16), (1, 24)):
+        run(False, fused_resume=res, fused_kb=16, fused_kn=8, fused_kr=kr)
+    run(True, fused_resume=1, fused_kb=16, fused_kn=8, fused_kr=8)
+if "--grid" in sys.argv:
+    for kb in (12, 16, 24, 32):
+        for kn in (4, 8, 12):
+            for kr in (16, 24, 32, 40, 48):
+                run(False, fused_resume=1, fused_kb=kb, fused_kn=kn, fused_kr=kr)
+    run(False, fused_resume=0, fused_kr=1)
+if "--ab" in sys.argv:  # RESUME on/off on the chosen scene
+    for res in (0, 1, 0, 1):
+        run(False, fused_resume=res)
+if "--grid5" in sys.argv:
+    for kb in (8, 16, 24, 32):
+        for kn in (4, 8, 16):
+            for kr in (8, 16, 32):
+                run(False, fused_resume=1, fused_kb=kb, fused_kn=kn, fused_kr=kr)
+    run(False, fused_resume=0, fused_kr=1)
+    run(False, fused_resume=0, fused_kr=16)
