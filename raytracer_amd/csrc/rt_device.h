@@ -576,23 +576,25 @@ template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, bool participating, uint32_t features,
                                                 d3 o, d3 d, double time, double tmin, StackT* stack, int stride,
                                                 TravCounters* cnt, PathRng& rng, uint32_t min_busy, uint32_t kn) {
+  if (!participating) ts.cur = RT_DONE;  // lanes without a path: nothing to walk (keeps the loop predicates to one compare)
   while (true) {
-    const bool busy = participating && ts.cur != RT_DONE;
-    const unsigned long long m_busy = wave_ballot(busy);
+    const unsigned long long m_busy = wave_ballot(ts.cur != RT_DONE);
     if ((uint32_t)__popcll(m_busy) < min_busy) break;
-    unsigned long long m_node = wave_ballot(ts.cur >= 0) & m_busy;
+    bool at_node = ts.cur >= 0;
+    unsigned long long m_node = wave_ballot(at_node);
     const uint32_t need = (m_node != m_busy) ? kn : 1u;
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();
     while ((uint32_t)__popcll(m_node) >= need) {
-      if (busy && ts.cur >= 0) {
+      if (at_node) {
         if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
         node_step(acc, ts, stack, stride);
       }
-      m_node = wave_ballot(ts.cur >= 0) & m_busy;
+      at_node = ts.cur >= 0;
+      m_node = wave_ballot(at_node);
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
-    if (busy && ts.cur < 0 && ts.cur != RT_DONE) {
+    if (ts.cur < 0 && ts.cur != RT_DONE) {
       if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
       leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
