@@ -859,9 +859,11 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
   h.front = dot(tof(d), n) < 0.f;
   if (!h.front) n = -1.0f * n;
   uint32_t r[2] = {rng_next(rng), rng_next(rng)};
+  // one unit-sphere sample for whichever material needs it (Lambertian, Metal fuzz, isotropic): computed once for
+  // the wave instead of once per divergent material branch
+  const f3 u = sample_unit_sphere(r[0], r[1]);
   f3 att, dir;
   if (kind == 0u) {  // Lambertian (materials.rs:28-43)
-    f3 u = sample_unit_sphere(r[0], r[1]);
     dir = n + u;
     const float th = 1e-9f;
     if (__builtin_fabsf(dir.x) < th && __builtin_fabsf(dir.y) < th && __builtin_fabsf(dir.z) < th) dir = n;
@@ -870,7 +872,6 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
   } else if (kind == 1u) {  // Metal (materials.rs:73-80): reflects the UN-normalised direction, adds fuzz * unit
     f3 df = tof(d);
     f3 refl = df - (2.0f * dot(df, n)) * n;
-    f3 u = sample_unit_sphere(r[0], r[1]);
     dir = refl + M.fuzz * u;
     att = {M.albedo[0], M.albedo[1], M.albedo[2]};
   } else if (kind == 2u) {  // Dielectric (materials.rs:104-141)
@@ -899,7 +900,7 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
     out.radiance = {thr.x * e.x, thr.y * e.y, thr.z * e.z};
     return out;
   } else {  // EXT isotropic
-    dir = sample_unit_sphere(r[0], r[1]);
+    dir = u;
     if (M.tex < 0) att = {M.albedo[0], M.albedo[1], M.albedo[2]};
     else att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);
   }
