@@ -99,3 +99,30 @@ def test_c5_final_scene_4k_one_spp_is_sane(ctx):
     lit = (a.sum(axis=2) > 0).mean()
     assert 0.01 < lit < 0.5  # dark scene, one small area light, no next-event estimation: few 1-spp paths find it
     assert np.array_equal(a, dev.render_sums(cam, seed=2))
+
+
+def test_c2_traversal_schedules_agree(ctx, c2):
+    """Resumable (default for this scene size) vs bounce-synchronous traversal: the same paths in a different lane
+    schedule.  Both are bit-reproducible; between them only the f32 shading code's contraction may differ."""
+    host, dev, cam = c2
+    a = dev.render_sums(cam, seed=3)
+    rays_a = ctx.stats()["rays"]
+    ctx.set_option("fused_resume", 0)
+    try:
+        b = dev.render_sums(cam, seed=3)
+        rays_b = ctx.stats()["rays"]
+        b2 = dev.render_sums(cam, seed=3)
+    finally:
+        ctx.set_option("fused_resume", 2)
+    assert np.array_equal(b, b2)
+    assert abs(rays_a - rays_b) <= 1e-4 * rays_a
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    close = np.isclose(a64, b64, rtol=1e-4, atol=1e-3).all(axis=2).mean()
+    assert close > 0.98 and abs(a64.sum() - b64.sum()) < 2e-4 * a64.sum()
+    # the thresholds only reorder work: any setting gives the identical frame
+    ctx.set_option("fused_kb", 40); ctx.set_option("fused_kn", 2); ctx.set_option("fused_kr", 3)
+    try:
+        c = dev.render_sums(cam, seed=3)
+    finally:
+        ctx.set_option("fused_kb", 16); ctx.set_option("fused_kn", 8); ctx.set_option("fused_kr", 16)
+    assert np.array_equal(a, c) and ctx.stats()["rays"] == rays_a
