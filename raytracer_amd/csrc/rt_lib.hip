@@ -225,8 +225,11 @@ template <> struct AccOf<KIND_GENERIC> {
   static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return global_acc(sc); }
 };
 
+// Register budget: 4 waves/SIMD (128 VGPRs) — what a 1024-thread workgroup needs anyway; the 256-thread instances that
+// carry the noise / image / medium code (HBM-resident scenes: C5) run better at 3 waves/SIMD with 168 VGPRs and
+// 272 B of scratch than at 4 with 432 B (26.4 vs 32.6 ms on C5 at 4 spp; 2 waves / 243 VGPRs / no scratch: 30.9).
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
-__global__ __launch_bounds__(BLOCK, 4) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 : 4) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
                                                  unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
   TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
