@@ -75,3 +75,6 @@ if "--grid5" in sys.argv:
                 run(False, fused_resume=1, fused_kb=kb, fused_kn=kn, fused_kr=kr)
     run(False, fused_resume=0, fused_kr=1)
     run(False, fused_resume=0, fused_kr=16)
+if "--lds" in sys.argv:  # LDS-resident vs HBM-resident instance on the chosen scene
+    for v in (1, 0, 1, 0):
+        run(False, fused_lds=v)
