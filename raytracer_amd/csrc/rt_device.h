@@ -212,6 +212,10 @@ __device__ __forceinline__ void slab_select(const SlabRay& s, float4 q0, float4 
   qz = s.sz ? float4{q1.y, q2.w, q0.z, q2.x} : float4{q0.z, q2.x, q1.y, q2.w};
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* LdsTablePtr;  // the noise jump table copied into LDS (k_fused)
+typedef const u32x4* GlobalTablePtr;
+
 // ----------------------------------------------------------------------------------------------- scene accessors
 // Where the traversal data lives.  GlobalAcc reads HBM/L2 through the vector cache; LdsAcc reads a
 // per-workgroup copy of the whole scene (nodes + 64-B sphere records) in LDS.
@@ -224,6 +228,7 @@ struct GlobalAcc {
   const BvhNode* nodes;
   const Prim* prims;
   static constexpr bool kSpheresOnly = false;
+  __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r; }
   __device__ __forceinline__ void node_slabs(int32_t i, const SlabRay& s, float4& qx, float4& qy, float4& qz,
                                              int2& ch) const {
@@ -244,6 +249,7 @@ struct SphereAcc {
   const float4* nodes;
   const SphereRec* spheres;
   static constexpr bool kSpheresOnly = true;
+  __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r; }
   __device__ __forceinline__ void node_slabs(int32_t i, const SlabRay& s, float4& qx, float4& qy, float4& qz,
                                              int2& ch) const {
@@ -272,7 +278,9 @@ struct SphereAcc {
 struct SlabLdsAcc {
   const unsigned char* nodes;
   const SphereRec* spheres;
+  LdsTablePtr noise;  // LDS copy of the noise jump table (scenes with a noise texture)
   static constexpr bool kSpheresOnly = true;
+  __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
   __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
                                              int2& ch) const {
@@ -294,7 +302,9 @@ struct SlabLdsAcc {
 struct GenericLdsAcc {
   const unsigned char* nodes;
   const Prim* prims;
+  LdsTablePtr noise;
   static constexpr bool kSpheresOnly = false;
+  __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
   __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
                                              int2& ch) const {
@@ -652,14 +662,12 @@ __device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 
 // xoroshiro128+ short jump as a GF(2)-linear map: state' = XOR over the 16 state bytes of table[byte][value]
 // (the jump of random.rs:37-57 is linear, so its 128 conditional-XOR steps collapse to 16 table lookups).
 // XOR of the four table rows row0..row0+3 selected by the bytes of `word` (one 32-bit quarter of the state)
-__device__ __noinline__ uint4 noise_jump_part(const uint4* __restrict__ table, uint32_t word, int row0) {
-  uint4 acc = {0, 0, 0, 0};
+template <class TabT>
+__device__ __noinline__ uint4 noise_jump_part(TabT table, uint32_t word, int row0) {
+  u32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint4 e = table[(row0 + i) * 256 + ((word >> (i * 8)) & 0xffu)];
-    acc.x ^= e.x; acc.y ^= e.y; acc.z ^= e.z; acc.w ^= e.w;
-  }
-  return acc;
+  for (int i = 0; i < 4; i++) acc ^= table[(row0 + i) * 256 + ((word >> (i * 8)) & 0xffu)];
+  return uint4{acc.x, acc.y, acc.z, acc.w};
 }
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
 __device__ __forceinline__ double noise_value(uint4 st) {
@@ -672,7 +680,8 @@ __device__ __forceinline__ double noise_value(uint4 st) {
 // The jump is linear over GF(2), so the state splits into parts that depend on x only (2 values), on y only
 // (2 values) and on (y's sign, z) (4 values): 40 table lookups for the 8 corners instead of 128.
 // Corner k: x bit 0, z bit 1, y bit 2 (order of texture.rs:130-137).
-__device__ __forceinline__ void noise_corners_dev(const uint4* __restrict__ table, int32_t ix, int32_t iy, int32_t iz,
+template <class TabT>
+__device__ __forceinline__ void noise_corners_dev(TabT table, int32_t ix, int32_t iy, int32_t iz,
                                                   double c[8]) {
   uint4 tx[2], ty[2], tz[4];
 #pragma unroll
@@ -747,7 +756,7 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
       double fx = rem_euclid1(x), fy = rem_euclid1(y), fz = rem_euclid1(z);
       double xb = fx * fx * (3.0 - 2.0 * fx), yb = fy * fy * (3.0 - 2.0 * fy), zb = fz * fz * (3.0 - 2.0 * fz);
       double c[8];
-      noise_corners_dev(sc.noise_table, ix, iy, iz, c);
+      noise_corners_dev(acc.noise_table(sc), ix, iy, iz, c);
       auto lerp = [](double a, double b, double w) { return (1.0 - w) * a + w * b; };  // color.rs:62-64
       double m00 = lerp(c[0], c[1], xb), m01 = lerp(c[2], c[3], xb);
       double m10 = lerp(c[4], c[5], xb), m11 = lerp(c[6], c[7], xb);

@@ -193,6 +193,7 @@ struct FusedParams {
   uint32_t k0, k1;
   uint32_t stack_depth;
   uint32_t kb, kn;  // RESUME variant: hand-back / node-loop exit thresholds (traverse_resume)
+  uint32_t noise_lds;  // the LDS-resident instances copy the noise jump table into LDS (scene has a noise texture)
   uint32_t kr;      // regenerate only when at least kr lanes are free (or none carries a path)
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
@@ -208,21 +209,21 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
 template <int KIND> struct AccOf;
 template <> struct AccOf<KIND_SPHERES_LDS> {
   using type = SlabLdsAcc;
-  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls) { return type{ln, ls}; }
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls, LdsTablePtr nt) { return type{ln, ls, nt}; }
 };
 template <> struct AccOf<KIND_GENERIC_LDS> {
   using type = GenericLdsAcc;
-  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp) {
-    return type{ln, reinterpret_cast<const Prim*>(lp)};
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp, LdsTablePtr nt) {
+    return type{ln, reinterpret_cast<const Prim*>(lp), nt};
   }
 };
 template <> struct AccOf<KIND_SPHERES_GLOBAL> {
   using type = SphereAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return sphere_acc(sc); }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return sphere_acc(sc); }
 };
 template <> struct AccOf<KIND_GENERIC> {
   using type = GlobalAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*) { return global_acc(sc); }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return global_acc(sc); }
 };
 
 // Register budget: 4 waves/SIMD (128 VGPRs) — what a 1024-thread workgroup needs anyway; the 256-thread instances that
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   size_t off = 0;
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
+  LdsTablePtr l_noise = nullptr;
   if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) {
     off += RT_SLAB_REGION_BYTES(sc.n_nodes);
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
@@ -251,12 +253,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
                                                 : reinterpret_cast<const float4*>(sc.prims);
     float4* ls = reinterpret_cast<float4*>(l_sph);
     for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
+    if ((F & RT_F_TEX_NOISE) && fp.noise_lds) {  // 64 KB noise jump table: 40 random 16-B lookups per noise sample
+      uint4* lt = reinterpret_cast<uint4*>(smem + off);
+      l_noise = (LdsTablePtr)(reinterpret_cast<u32x4*>(lt));
+      off += 16 * 256 * 16;
+      for (int i = threadIdx.x; i < 16 * 256; i += BLOCK) lt[i] = sc.noise_table[i];
+    }
   }
   unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
   off += (size_t)(BLOCK / 64) * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
   if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) __syncthreads();
-  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph);
+  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
 
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long my_rays = 0;
@@ -1180,9 +1188,11 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   const bool small_ids = (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768 && scene->view.n_prims < 32000;  // int16 stack entries
   int rc;
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
-  const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64;
+  const size_t lds_noise = (scene->features & RT_F_TEX_NOISE) ? (size_t)16 * 256 * 16 : 0;
+  fp.noise_lds = lds_noise ? 1u : 0u;
+  const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64 + lds_noise;
   const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
-  const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 +
+  const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_noise +
                                   16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   StageTimer tm(ctx, st);
   tm.begin();
