@@ -1203,6 +1203,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
       else rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true, false>(ctx, scene, dc, fp, lds_1024, st);
     } else if (lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
     else if (tex_only == RT_F_TEX_IMAGE) rc = launch_variant<RT_F_TEX_IMAGE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else if (!(tex_only & RT_F_TEX_IMAGE)) rc = launch_variant<RT_F_TEX_CHECKER | RT_F_TEX_NOISE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
     else rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
   } else if (!scene->spheres_only && ctx->fused_lds && small_ids && lds_generic_1024 <= 160 * 1024) {
     if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
