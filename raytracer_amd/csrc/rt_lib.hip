@@ -230,9 +230,12 @@ template <> struct AccOf<KIND_GENERIC> {
 // carry the noise / image / medium code (HBM-resident scenes: C5) run better at 3 waves/SIMD with 168 VGPRs and
 // 272 B of scratch than at 4 with 432 B (26.4 vs 32.6 ms on C5 at 4 spp; 2 waves / 243 VGPRs / no scratch: 30.9).
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 : 4) void k_fused(Scene sc, Camera cam, FusedParams fp, uint32_t* __restrict__ unit_counter,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 : 4) void k_fused(Scene sc, const Camera* __restrict__ camp, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
                                                  unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
+  // The camera block (26 doubles) stays in memory: read with scalar loads where a ray is generated instead of
+  // occupying ~60 SGPRs for the whole kernel (they spilled to VGPR lanes: 68 v_readlane per regeneration).
+  struct { uint32_t width, height, max_depth; } cam = {camp->width, camp->height, camp->max_depth};
   TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
   float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
   uint64_t st_t0 = 0, st_tk = 0;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   // shade one finished traversal; returns true when the path continues with a new ray in (o, d)
   auto bounce = [&](HitInfo hit) -> bool {
     if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
-    ShadeOut so = shade<F>(sc, acc, cam, o, d, time, thr, hit, rng);
+    ShadeOut so = shade<F>(sc, acc, *camp, o, d, time, thr, hit, rng);
     if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
     if (!so.alive) {
       const unsigned long long r = to_fix(so.radiance.x), g = to_fix(so.radiance.y), b = to_fix(so.radiance.z);
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
       }
       uint32_t u = 0;
       if (lane == 0) u = atomicAdd(unit_counter, 1u);
-      u = __shfl(u, 0, 64);
+      u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);  // scalar: the unit bookkeeping below stays in SGPRs
       if (u >= fp.n_units) {
         exhausted = true;
         have_unit = false;
@@ -362,7 +365,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
           if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
           uint32_t pixel = py * cam.width + px;
           uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
-          generate_ray(cam, pixel, s, fp.k0, fp.k1, o, d, time, rng);
+          const Camera* cp = camp;
+          asm volatile("" : "+s"(cp));  // keep the camera loads here (not hoisted into long-lived SGPRs)
+          generate_ray(*cp, pixel, s, fp.k0, fp.k1, o, d, time, rng);
           thr = {1.f, 1.f, 1.f};
           depth = 0;
           lpix = pit;
@@ -518,6 +523,7 @@ struct rt_ctx {
   float* d_dbg = nullptr;
   WorkBuffers wb;
   uint32_t* d_unit_counter = nullptr;
+  Camera* d_cam = nullptr;  // camera block of the render in flight (fused mode reads it with scalar loads)
   unsigned long long* d_fbacc = nullptr;
   size_t fbacc_cap = 0;
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
@@ -602,6 +608,7 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_unit_counter, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->d_dbg, 0, 16 * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
@@ -636,6 +643,7 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
   if (ctx->d_ray_total) (void)hipFree(ctx->d_ray_total);
   if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
+  if (ctx->d_cam) (void)hipFree(ctx->d_cam);
   if (ctx->d_fbacc) (void)hipFree(ctx->d_fbacc);
   if (ctx->d_trav) (void)hipFree(ctx->d_trav);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
@@ -1141,7 +1149,8 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   chunks = (fp.K + fp.Ku - 1) / fp.Ku;
   fp.n_units = fp.n_tiles * chunks;
   const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, dc, fp, ctx->d_unit_counter, ctx->d_fbacc,
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cam, &dc, sizeof(Camera), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->d_cam, fp, ctx->d_unit_counter, ctx->d_fbacc,
                      ctx->d_ray_total, ctx->d_dbg);
   HIP_TRY(ctx, hipGetLastError());
   return RT_OK;
