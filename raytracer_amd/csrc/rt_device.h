@@ -229,6 +229,8 @@ struct GlobalAcc {
   const Prim* prims;
   static constexpr bool kSpheresOnly = false;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
+  __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
+  __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r; }
   __device__ __forceinline__ void node_slabs(int32_t i, const SlabRay& s, float4& qx, float4& qy, float4& qz,
                                              int2& ch) const {
@@ -250,6 +252,8 @@ struct SphereAcc {
   const SphereRec* spheres;
   static constexpr bool kSpheresOnly = true;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
+  __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
+  __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r; }
   __device__ __forceinline__ void node_slabs(int32_t i, const SlabRay& s, float4& qx, float4& qy, float4& qz,
                                              int2& ch) const {
@@ -279,7 +283,11 @@ struct SlabLdsAcc {
   const unsigned char* nodes;
   const SphereRec* spheres;
   LdsTablePtr noise;  // LDS copy of the noise jump table (scenes with a noise texture)
+  const Material* l_mats;  // LDS copies of the material / texture tables: the shade step's two dependent
+  const Texture* l_texs;   // fetches (material, then its texture) cost LDS instead of L2 latency
   static constexpr bool kSpheresOnly = true;
+  __device__ __forceinline__ const Material* mats(const Scene&) const { return l_mats; }
+  __device__ __forceinline__ const Texture* texs(const Scene&) const { return l_texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
   __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
@@ -303,7 +311,11 @@ struct GenericLdsAcc {
   const unsigned char* nodes;
   const Prim* prims;
   LdsTablePtr noise;
+  const Material* l_mats;
+  const Texture* l_texs;
   static constexpr bool kSpheresOnly = false;
+  __device__ __forceinline__ const Material* mats(const Scene&) const { return l_mats; }
+  __device__ __forceinline__ const Texture* texs(const Scene&) const { return l_texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
   __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
@@ -721,7 +733,7 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
   // texture.rs:55-66: a checker selects a child by the parity of floor(p*inv_scale); children may nest.
 #pragma unroll 1
   for (int guard = 0; guard < 8; guard++) {
-    const Texture& T = sc.texs[ti];
+    const Texture& T = acc.texs(sc)[ti];
     const uint32_t kind = T.kind;
     if (kind == 0u) return {T.rgb[0], T.rgb[1], T.rgb[2]};  // texture.rs:32-36
     if ((F & RT_F_TEX_CHECKER) && kind == 1u) {
@@ -847,7 +859,7 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
     out.radiance = {thr.x * c.x, thr.y * c.y, thr.z * c.z};
     return out;
   }
-  const Material& M = sc.mats[acc.mat(hit.prim)];
+  const Material& M = acc.mats(sc)[acc.mat(hit.prim)];
   const uint32_t kind = M.kind;
   // hit record (geometry.rs:58-64): the point stays f64 (it is the next ray's origin); the normal is only ever
   // used by f32 shading math, so it is formed from the f64 difference p - c scaled by an f32 reciprocal radius.

@@ -209,21 +209,31 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
 template <int KIND> struct AccOf;
 template <> struct AccOf<KIND_SPHERES_LDS> {
   using type = SlabLdsAcc;
-  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls, LdsTablePtr nt) { return type{ln, ls, nt}; }
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls, LdsTablePtr nt,
+                                              const Material* lm, const Texture* lt) {
+    return type{ln, ls, nt, lm, lt};
+  }
 };
 template <> struct AccOf<KIND_GENERIC_LDS> {
   using type = GenericLdsAcc;
-  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp, LdsTablePtr nt) {
-    return type{ln, reinterpret_cast<const Prim*>(lp), nt};
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp, LdsTablePtr nt,
+                                              const Material* lm, const Texture* lt) {
+    return type{ln, reinterpret_cast<const Prim*>(lp), nt, lm, lt};
   }
 };
 template <> struct AccOf<KIND_SPHERES_GLOBAL> {
   using type = SphereAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return sphere_acc(sc); }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr, const Material*,
+                                              const Texture*) {
+    return sphere_acc(sc);
+  }
 };
 template <> struct AccOf<KIND_GENERIC> {
   using type = GlobalAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return global_acc(sc); }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr, const Material*,
+                                              const Texture*) {
+    return global_acc(sc);
+  }
 };
 
 // Register budget: 4 waves/SIMD (128 VGPRs) — what a 1024-thread workgroup needs anyway; the 256-thread instances that
@@ -246,6 +256,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
   LdsTablePtr l_noise = nullptr;
+  const Material* l_mats = nullptr;
+  const Texture* l_texs = nullptr;
   if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) {
     off += RT_SLAB_REGION_BYTES(sc.n_nodes);
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
@@ -256,6 +268,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
                                                 : reinterpret_cast<const float4*>(sc.prims);
     float4* ls = reinterpret_cast<float4*>(l_sph);
     for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
+    {  // material (32 B) and texture (64 B) tables
+      float4* lm = reinterpret_cast<float4*>(smem + off);
+      l_mats = reinterpret_cast<const Material*>(lm);
+      off += (size_t)sc.n_mats * 32;
+      const float4* gm = reinterpret_cast<const float4*>(sc.mats);
+      for (int i = threadIdx.x; i < sc.n_mats * 2; i += BLOCK) lm[i] = gm[i];
+      float4* lt = reinterpret_cast<float4*>(smem + off);
+      l_texs = reinterpret_cast<const Texture*>(lt);
+      off += (size_t)sc.n_texs * 64;
+      const float4* gt = reinterpret_cast<const float4*>(sc.texs);
+      for (int i = threadIdx.x; i < sc.n_texs * 4; i += BLOCK) lt[i] = gt[i];
+    }
     if ((F & RT_F_TEX_NOISE) && fp.noise_lds) {  // 64 KB noise jump table: 40 random 16-B lookups per noise sample
       uint4* lt = reinterpret_cast<uint4*>(smem + off);
       l_noise = (LdsTablePtr)(reinterpret_cast<u32x4*>(lt));
@@ -267,7 +291,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   off += (size_t)(BLOCK / 64) * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
   if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) __syncthreads();
-  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
+  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise, l_mats, l_texs);
 
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long my_rays = 0;
@@ -840,6 +864,8 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   }
   rtb::BuildResult bvh = rtb::build_bvh(boxes, RT_STACK_DEPTH);
   sc->bvh_depth = bvh.depth;
+  if (getenv("RT_VERBOSE"))
+    fprintf(stderr, "[rt] scene: %zu prims, %zu nodes, BVH depth %d\n", boxes.size(), bvh.nodes.size(), bvh.depth);
   if (bvh.depth >= RT_STACK_DEPTH) return fail(ctx, RT_E_INTERNAL, "BVH deeper than the traversal stack");
 
   std::vector<Material> mats(d->n_materials);
@@ -882,6 +908,26 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       }
     }
   }
+  // Compact the device texture table: solid colours were inlined into their users above, so nothing refers to
+  // them by index any more (book_cover: 320 textures -> 1).  The table is small enough for LDS afterwards.
+  {
+    std::vector<int32_t> remap(texs.size(), -1);
+    std::vector<Texture> kept;
+    for (uint64_t i = 0; i < d->n_textures; i++) {
+      if (texs[i].kind == RT_TEX_SOLID) continue;
+      Texture t = texs[i];
+      if (t.kind == RT_TEX_CHECKER) {  // children precede their checker, so they are already remapped
+        if (t.odd >= 0) t.odd = remap[(size_t)t.odd];
+        if (t.even >= 0) t.even = remap[(size_t)t.even];
+      }
+      remap[i] = (int32_t)kept.size();
+      kept.push_back(t);
+    }
+    for (Material& m : mats)
+      if (m.tex >= 0) m.tex = remap[(size_t)m.tex];
+    if (kept.empty()) kept.emplace_back(Texture{});
+    texs.swap(kept);
+  }
   static_assert(sizeof(rtb::FlatNode) == sizeof(BvhNode), "node layout mismatch");
   size_t n_nodes = std::max<size_t>(bvh.nodes.size(), 1);
   HIP_TRY(ctx, hipMalloc(&sc->d_nodes, n_nodes * sizeof(BvhNode)));
@@ -921,7 +967,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   sc->view.n_nodes = (int32_t)bvh.nodes.size();
   sc->view.n_prims = (int32_t)prims.size();
   sc->view.n_mats = (int32_t)mats.size();
-  sc->view.n_texs = (int32_t)d->n_textures;
+  sc->view.n_texs = (int32_t)texs.size();
   sc->view.root = bvh.root;
   return RT_OK;
 }
@@ -1199,9 +1245,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
   const size_t lds_noise = (scene->features & RT_F_TEX_NOISE) ? (size_t)16 * 256 * 16 : 0;
   fp.noise_lds = lds_noise ? 1u : 0u;
-  const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64 + lds_noise;
+  const size_t lds_tables = (size_t)scene->view.n_mats * 32 + (size_t)scene->view.n_texs * 64 + lds_noise;
+  const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64 + lds_tables;
   const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
-  const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_noise +
+  const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_tables +
                                   16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   StageTimer tm(ctx, st);
   tm.begin();
