@@ -73,6 +73,7 @@ struct Scene {
 struct Camera {
   double center[3], pixel00[3], du[3], dv[3], dfu[3], dfv[3];
   double defocus_angle;
+  double grid_interval, grid_offset;  // Uniform sampler: 1/n and 1/(2n) + 0.5 (mod.rs:153-157), computed once on the host
   float background[3];
   uint32_t width, height, sampler_kind, sampler_n, max_depth, background_mode;
 };
@@ -792,9 +793,9 @@ __device__ __forceinline__ f3 sample_unit_sphere(uint32_t r0, uint32_t r1) {
 
 // Camera::sample_point (src/camera/mod.rs:176-186) + sample_pixel's sub-pixel position (mod.rs:150-172) for
 // sample index s of pixel (j = row, i = column).
-__device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t pixel, uint32_t s, uint32_t k0, uint32_t k1,
-                                             d3& o, d3& d, double& time, PathRng& rng) {
-  uint32_t j = pixel / cam.width, i = pixel - j * cam.width;
+__device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t j, uint32_t i, uint32_t s, uint32_t k0,
+                                             uint32_t k1, d3& o, d3& d, double& time, PathRng& rng) {
+  const uint32_t pixel = j * cam.width + i;
   uint32_t r[4];
   philox4x32_10(pixel, s, 0u, 0u, k0, k1, r);
   rng.s0 = r[2];
@@ -805,8 +806,7 @@ __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t pixel, 
     if (cam.sampler_kind == 0u) {  // Uniform(n): fixed grid, offset as in mod.rs:153-157
       uint32_t n = cam.sampler_n;
       uint32_t yi = s / n, xi = s - yi * n;
-      double interval = 1.0 / (double)n;
-      double offset = interval / 2.0 + 0.5;
+      const double interval = cam.grid_interval, offset = cam.grid_offset;
       dy = (double)j + (double)yi * interval - offset;
       dx = (double)i + (double)xi * interval - offset;
     } else {  // Random(n): dy then dx uniform in [-0.5, 0.5) (mod.rs:166-167)
@@ -896,12 +896,12 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
     dir = refl + M.fuzz * u;
     att = {M.albedo[0], M.albedo[1], M.albedo[2]};
   } else if (kind == 2u) {  // Dielectric (materials.rs:104-141)
-    float ratio = h.front ? 1.0f / M.ior : M.ior;
+    float ratio = h.front ? __builtin_amdgcn_rcpf(M.ior) : M.ior;
     f3 ud = normalize(tof(d));
     float cos_t = fminf(-dot(ud, n), 1.0f);
     float sin_t = __builtin_sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
     bool cannot = ratio * sin_t > 1.0f;
-    float r0 = (1.f - ratio) / (1.f + ratio);
+    float r0 = (1.f - ratio) * __builtin_amdgcn_rcpf(1.f + ratio);
     r0 = r0 * r0;
     float m = 1.f - cos_t;
     float refl_p = r0 + (1.f - r0) * (m * m * m * m * m);

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Camera cam, Queue q, floa
     d3 o, d;
     double time;
     PathRng rng;
-    generate_ray(cam, pixel, s, pp.k0, pp.k1, o, d, time, rng);
+    generate_ray(cam, pixel / cam.width, pixel % cam.width, s, pp.k0, pp.k1, o, d, time, rng);
     q.r0[i] = rng.s0; q.r1[i] = rng.s1;
     q.ox[i] = o.x; q.oy[i] = o.y; q.oz[i] = o.z;
     q.dx[i] = d.x; q.dy[i] = d.y; q.dz[i] = d.z;
@@ -387,11 +387,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
         uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
         if (px < cam.width && py < cam.height) {
           if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
-          uint32_t pixel = py * cam.width + px;
           uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
           const Camera* cp = camp;
           asm volatile("" : "+s"(cp));  // keep the camera loads here (not hoisted into long-lived SGPRs)
-          generate_ray(*cp, pixel, s, fp.k0, fp.k1, o, d, time, rng);
+          generate_ray(*cp, py, px, s, fp.k0, fp.k1, o, d, time, rng);
           thr = {1.f, 1.f, 1.f};
           depth = 0;
           lpix = pit;
@@ -1082,6 +1081,8 @@ static int to_device_camera(rt_ctx* ctx, const rt_camera* c, Camera& o) {
   if (!finite3(c->center) || !finite3(c->pixel00) || !finite3(c->du) || !finite3(c->dv))
     return fail(ctx, RT_E_INVALID_ARG, "camera: non-finite frame vectors");
   o.defocus_angle = c->defocus_angle;
+  o.grid_interval = 1.0 / (double)c->sampler_n;
+  o.grid_offset = o.grid_interval / 2.0 + 0.5;
   o.width = c->width; o.height = c->height; o.sampler_kind = c->sampler_kind; o.sampler_n = c->sampler_n;
   o.max_depth = c->max_depth; o.background_mode = c->background_mode;
   return RT_OK;
