@@ -5,14 +5,14 @@ configs[1] (book_cover: bouncing spheres + motion blur + checker ground, 1200x67
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full render of the frame: every rank renders the residue class `s % N == rank` of the
-per-pixel sample indices for the WHOLE frame (weak: N x the samples => `--scale-spp`; default strong split of the
-config's 100 spp is not used — see `scaling` below), the partial f32 frames are summed on rank 0 with one RCCL
-reduce, and rank 0 resolves (mean, gamma 2.2, 8-bit).  Scene and camera are resident in HBM before the timed
-region; outputs stay on the device.
+A "step" is one full render of the frame on every rank: each rank renders ALL of the config's per-pixel sample
+indices (100 spp) for the whole frame with its own Philox key (decorrelated streams per GPU), the partial f32
+frames are summed on rank 0 with one RCCL reduce, and rank 0 resolves (mean over N x 100 samples, gamma 2.2,
+8-bit).  Scene and camera are resident in HBM before the timed region; outputs stay on the device.
 
-Scaling is WEAK: each rank always renders the config's full 100 spp share (`spp_per_gpu` = 100), i.e. at N
-GPUs the frame converges with N x 100 spp; value = total samples of all ranks / max-over-ranks time.
+Scaling is therefore WEAK (per-GPU work fixed: `spp_per_gpu` = 100; at N GPUs the frame converges with N x 100
+spp); value = samples of all ranks / max-over-ranks time.  (A fixed sample budget is split by residue class of the
+sample index instead — `rt_render(..., sample_begin = rank, sample_stride = N)`, raytracer_amd/multi_gpu.py.)
 
 The JSON line also carries
   roofline      FP32-VALU roofline of the render kernels (algorithmic flops/sample from the
@@ -194,7 +194,7 @@ def main():
         }
         if stage:
             out["roofline"]["stage_ms"] = stage
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would idle on it)
             out["cpu_baseline"] = cpu_baseline(scene_name, width, depth, texels)
         print(json.dumps(out), flush=True)
     if world > 1:
