@@ -501,20 +501,21 @@ __device__ __forceinline__ void trav_init(TravState& ts, int32_t root, d3 o, d3 
   trav_restart(ts, root);
   trav_ray_constants(ts, o, d);
 }
+// Stack with its top entry cached in a register.  `sp` counts the entries including the cached one; LDS slot k
+// holds entry k for k < sp - 1.  Both operations are branch-free: a push with an empty stack stores the (dead)
+// cached value into slot 0, a pop with fewer than two entries reads slot 0 and discards it.
 template <class StackT>
 __device__ __forceinline__ void trav_push(TravState& ts, int32_t v, StackT* stack, int stride) {
-  if (ts.sp > 0) stack[(ts.sp - 1) * stride] = (StackT)ts.top;
+  stack[max(ts.sp - 1, 0) * stride] = (StackT)ts.top;
   ts.top = v;
   ts.sp++;
 }
 template <class StackT>
 __device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int stride) {
   ts.cur = ts.top;  // RT_DONE when the stack is empty
-  ts.top = RT_DONE;
-  if (ts.sp > 0) {
-    ts.sp--;
-    if (ts.sp > 0) ts.top = (int32_t)stack[(ts.sp - 1) * stride];
-  }
+  const int32_t below = (int32_t)stack[max(ts.sp - 2, 0) * stride];
+  ts.top = ts.sp >= 2 ? below : RT_DONE;
+  ts.sp = max(ts.sp - 1, 0);
 }
 // precondition: ts.cur >= 0
 template <class Acc, class StackT>
