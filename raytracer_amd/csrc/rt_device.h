@@ -218,8 +218,9 @@ typedef const __attribute__((address_space(3))) u32x4* LdsTablePtr;  // the nois
 typedef const u32x4* GlobalTablePtr;
 
 // ----------------------------------------------------------------------------------------------- scene accessors
-// Where the traversal data lives.  GlobalAcc reads HBM/L2 through the vector cache; LdsAcc reads a
-// per-workgroup copy of the whole scene (nodes + 64-B sphere records) in LDS.
+// Where the traversal data lives.  GlobalAcc / SphereAcc read HBM/L2 through the vector cache (64-B nodes, plane
+// order by select); SlabLdsAcc / GenericLdsAcc read a per-workgroup copy of the whole scene in LDS (112-B slab
+// nodes, primitive records, material / texture tables and, when the scene has one, the noise jump table).
 struct PrimGeom {  // what the sphere path needs
   d3 c0, c1;
   double r;
