@@ -27,7 +27,7 @@ struct __attribute__((aligned(128))) Prim {  // 128 B
   // SPHERE / MOVING_SPHERE: f[0..2]=center0, f[3..5]=center1, f[6]=radius
   // QUAD: f[0..2]=Q, f[3..5]=u, f[6..8]=v, f[9..11]=unit normal, f[12]=D, f[13]=1/|u x v|
   // MEDIUM_SPHERE: f[0..2]=center, f[6]=radius, f[12]=-1/density
-  // MEDIUM_BOX: f[0..2]=corner, f[3..5],f[6..8],f[9..11]=edges, f[12]=-1/density
+  // MEDIUM_BOX: f[0..2]=corner, f[3..5],f[6..8],f[9..11]=edges / |edge|^2, f[12]=-1/density
   double f[14];
   uint32_t type, mat;
   int32_t obj;
@@ -361,6 +361,13 @@ struct TravCounters {
 __device__ __forceinline__ uint64_t now_cycles() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ float wave_share() { return 1.0f / (float)__popcll(__ballot(1)); }
 
+// 1/x to ~1 ulp: hardware seed (v_rcp_f64) + two Newton steps; x in the normal range, either sign
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
 // src/hittable/geometry.rs:36-57 — sphere quadratic in f64, evaluated in the reference's operation order
 // with contraction off so that `t` is bit-identical to the CPU path for identical inputs.
 #pragma clang fp contract(off)
@@ -397,7 +404,7 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
   d3 n = {P.f[9], P.f[10], P.f[11]};
   double denom = n.x * d.x + n.y * d.y + n.z * d.z;
   if (__builtin_fabs(denom) < 1e-8) return false;
-  double t = (P.f[12] - (n.x * o.x + n.y * o.y + n.z * o.z)) / denom;
+  double t = (P.f[12] - (n.x * o.x + n.y * o.y + n.z * o.z)) / denom;  // true division: edge-on rays decide by the last ulp
   if (!(tmin < t && t < tmax)) return false;
   d3 p = {o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
   d3 ph = {p.x - P.f[0], p.y - P.f[1], p.z - P.f[2]};
@@ -418,8 +425,8 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
 // conventions): boundary entry/exit over (-inf, inf) and (t1 + 1e-4, inf); clamp to the query range; scatter
 // distance -ln(u)/density in units of |d|.  One RNG draw per test.  Sphere boundary or oriented box
 // (corner + three orthogonal edges: an instance-transformed box baked at flatten time).
-__device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, double tmin, double tmax, PathRng& rng,
-                                           double& t_out) {
+__device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, double inv_a, double tmin, double tmax,
+                                           PathRng& rng, double& t_out) {
   double t1, t2;
   if (P.type == 3u) {
     d3 oc = {o.x - P.f[0], o.y - P.f[1], o.z - P.f[2]};
@@ -428,21 +435,21 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
     double disc = hb * hb - a * cc;
     if (disc < 0.) return false;
     double sq = __builtin_sqrt(disc);
-    t1 = (-hb - sq) / a;
-    t2 = (-hb + sq) / a;
+    t1 = (-hb - sq) * inv_a;
+    t2 = (-hb + sq) * inv_a;
   } else {
     d3 oq = {o.x - P.f[0], o.y - P.f[1], o.z - P.f[2]};
     t1 = -__builtin_inf();
     t2 = __builtin_inf();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      d3 e = {P.f[3 + 3 * k], P.f[4 + 3 * k], P.f[5 + 3 * k]};
-      double il = 1.0 / dot(e, e);
-      double so = dot(oq, e) * il, sd = dot(d, e) * il;
+      d3 e = {P.f[3 + 3 * k], P.f[4 + 3 * k], P.f[5 + 3 * k]};  // edge / |edge|^2 (scaled at upload)
+      double so = dot(oq, e), sd = dot(d, e);
       if (__builtin_fabs(sd) < 1e-300) {
         if (so < 0. || so > 1.) return false;
       } else {
-        double ta = (0. - so) / sd, tb = (1. - so) / sd;
+        const double isd = fast_rcp(sd);
+        double ta = (0. - so) * isd, tb = (1. - so) * isd;
         t1 = fmax(t1, fmin(ta, tb));
         t2 = fmin(t2, fmax(ta, tb));
       }
@@ -458,7 +465,7 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
   double dist_inside = (t2 - t1) * len;
   double hit_distance = P.f[12] * log(u01d(rng_next(rng)));
   if (hit_distance > dist_inside) return false;
-  t_out = t1 + hit_distance / len;
+  t_out = t1 + hit_distance * (len * inv_a);  // / len
   return true;
 }
 
@@ -476,13 +483,6 @@ struct TravState {
   double a, inv_a;  // |d|^2 (geometry.rs:43) and its reciprocal
   SlabRay s;
 };
-// 1/x to ~1 ulp: hardware seed (v_rcp_f64) + two Newton steps; x is |d|^2 of a ray (normal range, > 0)
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
-}
 // the part of the state that is a function of the ray alone (recomputed rather than kept across shading)
 __device__ __forceinline__ void trav_ray_constants(TravState& ts, d3 o, d3 d) {
   ts.a = d.x * d.x + d.y * d.y + d.z * d.z;
@@ -551,7 +551,7 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
     } else if ((features & RT_F_QUAD) && ty == 2u) {
       h = quad_hit(acc.full(pi), o, d, tmin, ts.best_t, t);
     } else if ((features & RT_F_MEDIUM) && ty >= 3u) {
-      h = medium_hit(acc.full(pi), o, d, ts.a, tmin, ts.best_t, rng, t);
+      h = medium_hit(acc.full(pi), o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t);
     }
   }
   if (h) {

@@ -851,7 +851,10 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
             return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": degenerate medium box edge");
         for (int a = 0; a < 3; a++) {
           q.f[a] = p.a[a];
-          q.f[3 + a] = p.b[a]; q.f[6 + a] = p.c[a]; q.f[9 + a] = p.d[a];
+          // device record: edges pre-divided by their squared length, so that dot(x, f[3+3k..]) is the box coordinate
+          // of x along edge k in [0, 1] without a division per test
+          for (int k = 0; k < 3; k++)
+            q.f[3 + 3 * k + a] = e[k][a] / (e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2]);
           double lo = p.a[a], hi = p.a[a];
           for (int k = 0; k < 3; k++) { lo += std::fmin(0.0, e[k][a]); hi += std::fmax(0.0, e[k][a]); }
           b.lo[a] = lo; b.hi[a] = hi;
