@@ -463,7 +463,8 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
   if (t1 < 0.) t1 = 0.;
   double len = __builtin_sqrt(a);
   double dist_inside = (t2 - t1) * len;
-  double hit_distance = P.f[12] * log(u01d(rng_next(rng)));
+  // free path -ln(u)/density: u is a 32-bit draw, so the hardware f32 logarithm (v_log_f32, ~1 ulp) loses nothing
+  double hit_distance = P.f[12] * (double)(__builtin_amdgcn_logf(u01f(rng_next(rng))) * 0.69314718056f);
   if (hit_distance > dist_inside) return false;
   t_out = t1 + hit_distance * (len * inv_a);  // / len
   return true;
