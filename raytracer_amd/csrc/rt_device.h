@@ -285,11 +285,9 @@ struct SlabLdsAcc {
   const unsigned char* nodes;
   const SphereRec* spheres;
   LdsTablePtr noise;  // LDS copy of the noise jump table (scenes with a noise texture)
-  const Material* l_mats;  // LDS copies of the material / texture tables: the shade step's two dependent
-  const Texture* l_texs;   // fetches (material, then its texture) cost LDS instead of L2 latency
   static constexpr bool kSpheresOnly = true;
-  __device__ __forceinline__ const Material* mats(const Scene&) const { return l_mats; }
-  __device__ __forceinline__ const Texture* texs(const Scene&) const { return l_texs; }
+  __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
+  __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
   __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,
@@ -313,11 +311,9 @@ struct GenericLdsAcc {
   const unsigned char* nodes;
   const Prim* prims;
   LdsTablePtr noise;
-  const Material* l_mats;
-  const Texture* l_texs;
   static constexpr bool kSpheresOnly = false;
-  __device__ __forceinline__ const Material* mats(const Scene&) const { return l_mats; }
-  __device__ __forceinline__ const Texture* texs(const Scene&) const { return l_texs; }
+  __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
+  __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? r * (RT_SLAB_NODE_BYTES / 16) : r; }
   __device__ __forceinline__ void node_slabs(int32_t ref, const SlabRay& s, float4& qx, float4& qy, float4& qz,

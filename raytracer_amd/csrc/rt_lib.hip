@@ -209,31 +209,23 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
 template <int KIND> struct AccOf;
 template <> struct AccOf<KIND_SPHERES_LDS> {
   using type = SlabLdsAcc;
-  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls, LdsTablePtr nt,
-                                              const Material* lm, const Texture* lt) {
-    return type{ln, ls, nt, lm, lt};
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* ls, LdsTablePtr nt) {
+    return type{ln, ls, nt};
   }
 };
 template <> struct AccOf<KIND_GENERIC_LDS> {
   using type = GenericLdsAcc;
-  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp, LdsTablePtr nt,
-                                              const Material* lm, const Texture* lt) {
-    return type{ln, reinterpret_cast<const Prim*>(lp), nt, lm, lt};
+  static __device__ __forceinline__ type make(const Scene&, const unsigned char* ln, const SphereRec* lp, LdsTablePtr nt) {
+    return type{ln, reinterpret_cast<const Prim*>(lp), nt};
   }
 };
 template <> struct AccOf<KIND_SPHERES_GLOBAL> {
   using type = SphereAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr, const Material*,
-                                              const Texture*) {
-    return sphere_acc(sc);
-  }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return sphere_acc(sc); }
 };
 template <> struct AccOf<KIND_GENERIC> {
   using type = GlobalAcc;
-  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr, const Material*,
-                                              const Texture*) {
-    return global_acc(sc);
-  }
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return global_acc(sc); }
 };
 
 // Register budget: 4 waves/SIMD (128 VGPRs) — what a 1024-thread workgroup needs anyway; the 256-thread instances that
@@ -256,8 +248,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
   LdsTablePtr l_noise = nullptr;
-  const Material* l_mats = nullptr;
-  const Texture* l_texs = nullptr;
   if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) {
     off += RT_SLAB_REGION_BYTES(sc.n_nodes);
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
@@ -268,18 +258,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
                                                 : reinterpret_cast<const float4*>(sc.prims);
     float4* ls = reinterpret_cast<float4*>(l_sph);
     for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
-    {  // material (32 B) and texture (64 B) tables
-      float4* lm = reinterpret_cast<float4*>(smem + off);
-      l_mats = reinterpret_cast<const Material*>(lm);
-      off += (size_t)sc.n_mats * 32;
-      const float4* gm = reinterpret_cast<const float4*>(sc.mats);
-      for (int i = threadIdx.x; i < sc.n_mats * 2; i += BLOCK) lm[i] = gm[i];
-      float4* lt = reinterpret_cast<float4*>(smem + off);
-      l_texs = reinterpret_cast<const Texture*>(lt);
-      off += (size_t)sc.n_texs * 64;
-      const float4* gt = reinterpret_cast<const float4*>(sc.texs);
-      for (int i = threadIdx.x; i < sc.n_texs * 4; i += BLOCK) lt[i] = gt[i];
-    }
     if ((F & RT_F_TEX_NOISE) && fp.noise_lds) {  // 64 KB noise jump table: 40 random 16-B lookups per noise sample
       uint4* lt = reinterpret_cast<uint4*>(smem + off);
       l_noise = (LdsTablePtr)(reinterpret_cast<u32x4*>(lt));
@@ -291,7 +269,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   off += (size_t)(BLOCK / 64) * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
   if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) __syncthreads();
-  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise, l_mats, l_texs);
+  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
 
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long my_rays = 0;
@@ -1249,7 +1227,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
   const size_t lds_noise = (scene->features & RT_F_TEX_NOISE) ? (size_t)16 * 256 * 16 : 0;
   fp.noise_lds = lds_noise ? 1u : 0u;
-  const size_t lds_tables = (size_t)scene->view.n_mats * 32 + (size_t)scene->view.n_texs * 64 + lds_noise;
+  const size_t lds_tables = lds_noise;  // material / texture records stay in HBM/L2: LDS copies bought nothing measurable
   const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64 + lds_tables;
   const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_tables +
