@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-stages", action="store_true", help="extra untimed step with per-stage hipEvents")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="rehearsal of the N>1 code path on a one-GPU box: every rank renders on GPU 0 and the "
+                         "partial frames are reduced with gloo through host memory (not a measurement)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,9 +90,14 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import raytracer_amd as ra
     scene_name, width, sampler, spp, depth, fixture = WORKLOADS[args.workload]
@@ -115,7 +123,11 @@ def main():
         # rank r draws from its own Philox key => decorrelated streams per GPU (north_star)
         seed = (seed0 + 0x9E3779B97F4A7C15 * (rank + 1) + i) & 0xFFFFFFFFFFFFFFFF
         dev_scene.render_device(cam, d_sum.data_ptr(), seed=seed, stream=stream)
-        if world > 1:
+        if world > 1 and args.rehearse:
+            h = d_sum.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            d_sum.copy_(h)
+        elif world > 1:
             dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
         if rank == 0:
             ctx.check(ctx.L.rt_resolve_device(ctx.h, d_sum.data_ptr(), W, H, host_scene.spp * world, 2.2, None,
@@ -153,7 +165,7 @@ def main():
         ctx.set_option("profile", 0)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -178,7 +190,7 @@ def main():
             "metric": "Msamples/sec (pixels x spp)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + f32 culling/shading",
-            "data": f"synthetic (scene builder {scene_name}, fixed seeds)",
+            "data": f"synthetic (scene builder {scene_name}, fixed seeds)" + (" REHEARSAL, not a measurement" if args.rehearse else ""),
             "config": {"workload": f"{args.workload}: {scene_name} {W}x{H}, {sampler}_sampler({host_scene.spp}), "
                                    f"depth {depth}, {host_scene.desc.n_prims} primitives",
                        "spp_per_gpu": host_scene.spp, "samples_per_step": samples_per_rank * world,
