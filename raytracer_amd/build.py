@@ -45,6 +45,16 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # C++ example driving the host layer the way the reference's main() does (examples/render_scene.cpp)
+    example_src = os.path.join(os.path.dirname(HERE), "examples", "render_scene.cpp")
+    example_bin = os.path.join(os.path.dirname(HERE), "examples", "render_scene")
+    if os.path.exists(example_src) and (force or _newer(example_bin, [example_src, LIB_HOST, os.path.join(HOST, "raytracer.hpp")])):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(os.path.dirname(HERE), "include"),
+               example_src, "-L" + HERE, "-lraytracer_host", "-lrt_mi355x", "-Wl,-rpath,$ORIGIN/../raytracer_amd",
+               "-o", example_bin]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return LIB_GPU, LIB_HOST
 
 

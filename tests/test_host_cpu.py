@@ -181,3 +181,15 @@ def test_ext_scenes_host_matches_oracle_structure(name):
         assert list(p["type"]) == [2] * 6 + [4, 4] and list(p["density"][6:]) == [0.01, 0.01]
     if name == "final_scene_small":
         assert (p["type"] == 3).sum() == 2 and (p["type"] == 1).sum() == 1
+
+
+def test_cpp_example_is_built_and_fails_cleanly_without_a_gpu():
+    """examples/render_scene.cpp = the reference's main() flow (main.rs:28-67) on the C++ host layer."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "examples", "render_scene")
+    assert os.path.exists(exe), "build it with python -m raytracer_amd.build"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present (the GPU run is tests/test_gpu_example.py)")
+    r = subprocess.run([exe, "two_spheres", "64", "4", "4", "/dev/null"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
