@@ -206,6 +206,10 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
   return (unsigned long long)(v * RT_FIX_SCALE);
 }
 
+__global__ void k_store_camera(Camera cam, Camera* __restrict__ dst) {
+  if (threadIdx.x == 0) *dst = cam;
+}
+
 template <int KIND> struct AccOf;
 template <> struct AccOf<KIND_SPHERES_LDS> {
   using type = SlabLdsAcc;
@@ -1177,7 +1181,9 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   chunks = (fp.K + fp.Ku - 1) / fp.Ku;
   fp.n_units = fp.n_tiles * chunks;
   const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cam, &dc, sizeof(Camera), hipMemcpyHostToDevice, st));
+  // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
+  // buffer has to outlive an asynchronous copy
+  hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->d_cam);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->d_cam, fp, ctx->d_unit_counter, ctx->d_fbacc,
                      ctx->d_ray_total, ctx->d_dbg);
   HIP_TRY(ctx, hipGetLastError());
