@@ -206,9 +206,13 @@ int rt_resolve_device(rt_ctx* ctx, const float* d_sum, uint32_t width, uint32_t 
 /* Counters / timings of the last render on this ctx.  Replaces: the wall-clock print of src/main.rs:51-57. */
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 
-/* Tunables: "max_paths" (paths in flight per pass), "profile" (1 = per-stage hipEvent timing, serialises
- * stages), "mode" (0 = wavefront kernels, 1 = fused persistent kernel), "bin_materials" (0/1).
- * Unknown keys return RT_E_INVALID_ARG.  No reference counterpart (constants are edited in main.rs:28-43). */
+/* Tunables.  "mode" (1 = fused persistent kernel, default; 0 = wavefront kernels), "max_paths" (wavefront: paths
+ * in flight per pass), "profile" (wavefront: 1 = per-stage hipEvent timing, serialises stages), "fused_ku" (samples
+ * per work unit, 0 = auto), "fused_lds" (1 = keep the scene in LDS when it fits), "fused_resume" (traversal
+ * schedule: 0 bounce-synchronous, 1 resumable, 2 = by scene size, default) with "fused_kb" / "fused_kn" /
+ * "fused_kr" (hand-back, node-loop exit and regeneration thresholds, 1..64), "fused_stats" (1 = instrumented
+ * kernel, fills rt_stats.dbg).  None of them changes the rendered frame.  Unknown keys and out-of-range values
+ * return RT_E_INVALID_ARG.  No reference counterpart (constants are edited in main.rs:28-43). */
 int rt_set_option(rt_ctx* ctx, const char* key, int64_t value);
 
 /* Host-side reference implementation of the counter-based generator used on the device (Philox4x32-10),
