@@ -179,13 +179,18 @@ def main():
         achieved = samples_per_rank * fps / (k_ms * 1e-3) / 1e12
         # HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE / WRITE_SIZE passes of
         # scripts/gpu_profile.sh, summarised by scripts/summarize_profile.py); only c2 is profiled
-        traffic = None
+        traffic, pmc_extra = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if args.workload == "c2" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                der = json.load(f).get("derived", {})
+                pmc = json.load(f)
+            der, cnt = pmc.get("derived", {}), pmc.get("counters", {})
             if "hbm_write_bytes" in der and "hbm_fetch_bytes_x2_upper" in der:
                 traffic = der["hbm_fetch_bytes_x2_upper"] + der["hbm_write_bytes"]
+            if "SQ_INSTS_VALU" in cnt:  # committed profile of the same command (not measured in this run)
+                pmc_extra = {"valu_wave_instructions_per_launch": cnt["SQ_INSTS_VALU"],
+                             "valu_active_lane_fraction": der.get("valu_active_lane_fraction"),
+                             "l2_hit_rate": der.get("l2_hit_rate"), "source": "profiles/pmc_latest.json"}
         out = {
             "metric": "Msamples/sec (pixels x spp)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -204,6 +209,8 @@ def main():
                          "kernel_ms_per_step": k_ms, "algorithmic_flops_per_sample": fps,
                          "rays_per_sample": stats["rays"] / max(stats["paths"], 1)},
         }
+        if pmc_extra:
+            out["roofline"]["pmc"] = pmc_extra
         if stage:
             out["roofline"]["stage_ms"] = stage
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would idle on it)
