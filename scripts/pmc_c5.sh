@@ -1,0 +1,10 @@
+# PMC passes on the HBM-resident workload (C5 final scene): L2 hit rate of the BVH / primitive fetches, HBM bytes,
+# VALU active-lane fraction
+set -e
+TAG=${1:-c5}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/$TAG
+timeout -s KILL 150 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/$TAG/pmc_l2 -o p -- python bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/$TAG/pmc_l2.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$TAG/pmc_fetch -o p -- python bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/$TAG/pmc_fetch.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$TAG/pmc_write -o p -- python bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/$TAG/pmc_write.log 2>&1
+timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/$TAG/pmc_a -o p -- python bench.py --workload c5 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/$TAG/pmc_a.log 2>&1
