@@ -126,3 +126,14 @@ def test_c2_traversal_schedules_agree(ctx, c2):
     finally:
         ctx.set_option("fused_kb", 16); ctx.set_option("fused_kn", 8); ctx.set_option("fused_kr", 16)
     assert np.array_equal(a, c) and ctx.stats()["rays"] == rays_a
+
+
+def test_c2_repeated_renders_stay_bit_identical(ctx, c2):
+    """Soak: 25 full-size renders — work-unit switches, straggler paths and accumulator flushes race-free means the
+    fixed-point frame never changes (any lost or doubled contribution would flip bits)."""
+    host, dev, cam = c2
+    ref = dev.render_sums(cam, seed=21)
+    rays = ctx.stats()["rays"]
+    for _ in range(24):
+        assert np.array_equal(dev.render_sums(cam, seed=21), ref)
+        assert ctx.stats()["rays"] == rays
