@@ -14,7 +14,8 @@ if scene_name in ("earth", "final_scene", "final_scene_small"):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     from golden_data import load_earth_rgba
     texels = load_earth_rgba()
-sc = ra.Scene(scene_name, width, 16 / 9, "uniform", spp, 50, texels=texels)
+sampler = next((a.split("=")[1] for a in sys.argv if a.startswith("--sampler=")), "uniform")
+sc = ra.Scene(scene_name, width, 16 / 9, sampler, spp, 50, texels=texels)
 dev = sc.upload(ctx)
 cam = sc.camera_copy()
 
