@@ -107,3 +107,27 @@ def test_background_modes(ctx):
     cam.background_mode = 0
     s0 = dev.render_sums(cam, seed=1) / 4.0
     assert (s0[..., 2] >= s0[..., 0] - 1e-6).all() and s0.min() >= 0.5 - 1e-6  # sky: white..(0.5,0.7,1.0)
+
+
+def test_traversal_schedule_does_not_change_ext_frames(ctx):
+    """Media draw random numbers INSIDE the traversal (SURVEY aX3); a lane's traversal order is its own, so the
+    resumable schedule and its thresholds must not change which numbers a path sees."""
+    from golden_data import load_earth_rgba
+    g = ra.Scene("final_scene_small", 160, 1.0, "uniform", 16, 30, texels=load_earth_rgba())
+    dev = g.upload(ctx)
+    cam = g.camera_copy()
+    a = dev.render_sums(cam, seed=4)
+    rays = ctx.stats()["rays"]
+    try:
+        ctx.set_option("fused_kb", 48); ctx.set_option("fused_kn", 3); ctx.set_option("fused_kr", 5)
+        b = dev.render_sums(cam, seed=4)
+        assert np.array_equal(a, b) and ctx.stats()["rays"] == rays
+        ctx.set_option("fused_resume", 0)
+        c = dev.render_sums(cam, seed=4).astype(np.float64)
+    finally:
+        ctx.set_option("fused_resume", 2)
+        ctx.set_option("fused_kb", 16); ctx.set_option("fused_kn", 8); ctx.set_option("fused_kr", 16)
+    a64 = a.astype(np.float64)
+    assert abs(ctx.stats()["rays"] - rays) <= 2e-3 * rays
+    assert np.isclose(a64, c, rtol=1e-4, atol=1e-3).all(axis=2).mean() > 0.97
+    assert abs(a64.sum() - c.sum()) < 5e-3 * a64.sum()
