@@ -230,6 +230,7 @@ struct GlobalAcc {
   const BvhNode* nodes;
   const Prim* prims;
   static constexpr bool kSpheresOnly = false;
+  static constexpr bool kPrimsInHbm = true;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -253,6 +254,7 @@ struct SphereAcc {
   const float4* nodes;
   const SphereRec* spheres;
   static constexpr bool kSpheresOnly = true;
+  static constexpr bool kPrimsInHbm = true;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -286,6 +288,7 @@ struct SlabLdsAcc {
   const SphereRec* spheres;
   LdsTablePtr noise;  // LDS copy of the noise jump table (scenes with a noise texture)
   static constexpr bool kSpheresOnly = true;
+  static constexpr bool kPrimsInHbm = false;
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -312,6 +315,7 @@ struct GenericLdsAcc {
   const Prim* prims;
   LdsTablePtr noise;
   static constexpr bool kSpheresOnly = false;
+  static constexpr bool kPrimsInHbm = false;
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -540,6 +544,19 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
   if (Acc::kSpheresOnly) {
     PrimGeom g = acc.sphere(pi);
     h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+  } else if (Acc::kPrimsInHbm) {
+    // one round trip: fetch the whole 128-B record (one cache line) before looking at its type, instead of
+    // type -> branch -> fields (two dependent L1/L2 latencies per leaf on a latency-bound instance)
+    const Prim P = acc.full(pi);
+    const uint32_t ty = P.type;
+    if (ty <= 1u) {
+      PrimGeom g = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, P.f[6], P.type, P.mat};
+      h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+    } else if ((features & RT_F_QUAD) && ty == 2u) {
+      h = quad_hit(P, o, d, tmin, ts.best_t, t);
+    } else if ((features & RT_F_MEDIUM) && ty >= 3u) {
+      h = medium_hit(P, o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t);
+    }
   } else {
     uint32_t ty = acc.type(pi);
     if (ty <= 1u) {
