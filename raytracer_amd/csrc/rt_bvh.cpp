@@ -170,4 +170,76 @@ BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth) {
   return res;
 }
 
+
+namespace {
+struct Cand {
+  int32_t ref;
+  float lo[3], hi[3];
+};
+float half_area(const Cand& c) {
+  const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+void children_of(const FlatNode& n, Cand& l, Cand& r) {
+  l.ref = n.left;
+  r.ref = n.right;
+  for (int a = 0; a < 3; a++) {
+    l.lo[a] = n.l_lo[a]; l.hi[a] = n.l_hi[a];
+    r.lo[a] = n.r_lo[a]; r.hi[a] = n.r_hi[a];
+  }
+}
+// returns the wide node's index; `need` = stack entries a traversal below this node can have pending
+int32_t collapse_rec(const BuildResult& bvh, int32_t n2, WideResult& out, int& need) {
+  Cand c[4];
+  int nc = 2;
+  children_of(bvh.nodes[(size_t)n2], c[0], c[1]);
+  while (nc < 4) {
+    int best = -1;
+    float best_area = -1.f;
+    for (int k = 0; k < nc; k++)
+      if (c[k].ref >= 0 && half_area(c[k]) > best_area) { best = k; best_area = half_area(c[k]); }
+    if (best < 0) break;
+    const int32_t opened = c[best].ref;
+    children_of(bvh.nodes[(size_t)opened], c[best], c[nc]);
+    nc++;
+  }
+  const int32_t me = (int32_t)out.nodes.size();
+  out.nodes.emplace_back();
+  int below = 0, used = 0;
+  int32_t child[4];
+  for (int k = 0; k < 4; k++) {
+    child[k] = EMPTY_CHILD;
+    if (k >= nc || c[k].ref == EMPTY_CHILD) continue;
+    used++;
+    if (c[k].ref >= 0) {
+      int sub = 0;
+      child[k] = collapse_rec(bvh, c[k].ref, out, sub);
+      below = std::max(below, sub);
+    } else {
+      child[k] = c[k].ref;
+    }
+  }
+  WideNode& w = out.nodes[(size_t)me];  // taken after the recursion: the vector may have grown
+  for (int k = 0; k < 4; k++) {
+    const bool live = child[k] != EMPTY_CHILD;
+    for (int a = 0; a < 3; a++) {
+      w.lo[a][k] = live ? c[k].lo[a] : std::numeric_limits<float>::infinity();
+      w.hi[a][k] = live ? c[k].hi[a] : -std::numeric_limits<float>::infinity();
+    }
+    w.child[k] = child[k];
+    w.pad[k] = 0;
+  }
+  need = std::max(used - 1, 0) + below;
+  return me;
+}
+}  // namespace
+
+WideResult collapse_bvh4(const BuildResult& bvh) {
+  WideResult out;
+  if (bvh.root < 0) return out;  // empty scene or a single primitive: nothing to collapse
+  out.nodes.reserve(bvh.nodes.size() / 2 + 1);
+  collapse_rec(bvh, bvh.root, out, out.stack_need);
+  return out;
+}
+
 }  // namespace rtb

@@ -29,4 +29,20 @@ struct BuildResult {
 // boxes[i] = f64 bounds of primitive i.  max_depth bounds the tree depth (traversal stack size).
 BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth);
 
+
+// Four-wide form of the same tree for the instances that traverse out of HBM/L2 (one 128-byte line per step, about
+// half as many dependent fetches per ray as the binary tree).  Structure of arrays: per axis the four children's
+// planes sit in one float4.  Unused slots have child == EMPTY_CHILD and an inverted (+inf, -inf) box.
+struct WideNode {  // mirrors the device layout (128 B)
+  float lo[3][4], hi[3][4];
+  int32_t child[4];  // >= 0: wide node index; < 0: ~prim; EMPTY_CHILD: unused slot
+  int32_t pad[4];
+};
+struct WideResult {
+  std::vector<WideNode> nodes;  // root is node 0 (when the binary tree has an inner root)
+  int stack_need = 0;           // most entries a nearest-first traversal can have pending
+};
+// Collapses the binary tree: each wide node adopts the grandchildren of its largest inner children until it has four.
+WideResult collapse_bvh4(const BuildResult& bvh);
+
 }  // namespace rtb

@@ -65,6 +65,7 @@ struct Scene {
   const Texture* texs;
   const uint32_t* texels;    // RGBA8
   const uint4* noise_table;  // 16 x 256 x 128-bit GF(2) table of the xoroshiro short jump
+  const float4* nodes4;      // four-wide form of the tree (128-B nodes, see WideAcc), root = node 0
   int32_t n_nodes, n_prims, n_mats, n_texs;
   int32_t root;  // >=0 node, <0 single leaf
   int32_t bvh_depth;
@@ -231,6 +232,7 @@ struct GlobalAcc {
   const Prim* prims;
   static constexpr bool kSpheresOnly = false;
   static constexpr bool kPrimsInHbm = true;
+  static constexpr bool kWide = false;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -255,6 +257,7 @@ struct SphereAcc {
   const SphereRec* spheres;
   static constexpr bool kSpheresOnly = true;
   static constexpr bool kPrimsInHbm = true;
+  static constexpr bool kWide = false;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -289,6 +292,7 @@ struct SlabLdsAcc {
   LdsTablePtr noise;  // LDS copy of the noise jump table (scenes with a noise texture)
   static constexpr bool kSpheresOnly = true;
   static constexpr bool kPrimsInHbm = false;
+  static constexpr bool kWide = false;
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -316,6 +320,7 @@ struct GenericLdsAcc {
   LdsTablePtr noise;
   static constexpr bool kSpheresOnly = false;
   static constexpr bool kPrimsInHbm = false;
+  static constexpr bool kWide = false;
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -335,6 +340,15 @@ struct GenericLdsAcc {
   }
   __device__ __forceinline__ const Prim& full(int32_t pi) const { return prims[pi]; }
   __device__ __forceinline__ uint32_t mat(int32_t pi) const { return prims[pi].mat; }
+};
+// HBM-resident scenes as k_fused walks them: the four-wide tree (128-B nodes: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4]
+// hi.z[4] child[4] pad), primitives and tables as in the base accessor.  Each step is one cache line and one memory
+// latency for four boxes; these instances are latency-bound, not issue-bound.
+template <class Base>
+struct WideAcc : Base {
+  const float4* nodes4;
+  static constexpr bool kWide = true;
+  __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? 0 : r; }
 };
 __device__ __forceinline__ void slab_node_store(unsigned char* l_nodes, int i, const BvhNode& n) {
   float4* w = reinterpret_cast<float4*>(l_nodes + (size_t)i * RT_SLAB_NODE_BYTES);
@@ -519,9 +533,53 @@ __device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int strid
   ts.top = ts.sp >= 2 ? below : RT_DONE;
   ts.sp = max(ts.sp - 1, 0);
 }
+// One step through a four-wide node: test the four boxes, continue with the nearest one hit and push the others
+// farthest first.  Unused slots never hit (child == RT_EMPTY_CHILD).
+#define RT_WIDE_CAS(i, j)                                  \
+  {                                                        \
+    const bool sw = t[j] < t[i];                           \
+    const float ti = t[i], tj = t[j];                      \
+    const int32_t ci = c[i], cj = c[j];                    \
+    t[i] = sw ? tj : ti; t[j] = sw ? ti : tj;              \
+    c[i] = sw ? cj : ci; c[j] = sw ? ci : cj;              \
+  }
+template <class Acc, class StackT>
+__device__ __forceinline__ void node_step_wide(const Acc& acc, TravState& ts, StackT* stack, int stride) {
+  const float4* np = acc.nodes4 + 8 * (size_t)ts.cur;
+  const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
+  const int4 ch = *reinterpret_cast<const int4*>(np + 6);
+  const SlabRay& s = ts.s;
+  const float4 ex = s.sx ? hix : lox, fx = s.sx ? lox : hix;  // entry / exit planes for the ray's direction
+  const float4 ey = s.sy ? hiy : loy, fy = s.sy ? loy : hiy;
+  const float4 ez = s.sz ? hiz : loz, fz = s.sz ? loz : hiz;
+  const float INF = __builtin_inff();
+  float t[4];
+  int32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+#define RT_WIDE_SLOT(k, m)                                                                                          \
+  {                                                                                                                 \
+    const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(ex.m, s.ix, -s.nx), __builtin_fmaf(ey.m, s.iy, -s.ny)),       \
+                                 __builtin_fmaf(ez.m, s.iz, -s.nz)), 0.f);                                          \
+    const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, s.ixw, -s.fx), __builtin_fmaf(fy.m, s.iyw, -s.fy)),     \
+                                 __builtin_fmaf(fz.m, s.izw, -s.fz)), ts.tmax_w);                                   \
+    t[k] = (tn <= tf && c[k] != RT_EMPTY_CHILD) ? tn : INF;                                                         \
+  }
+  RT_WIDE_SLOT(0, x) RT_WIDE_SLOT(1, y) RT_WIDE_SLOT(2, z) RT_WIDE_SLOT(3, w)
+#undef RT_WIDE_SLOT
+  RT_WIDE_CAS(0, 1) RT_WIDE_CAS(2, 3) RT_WIDE_CAS(0, 2) RT_WIDE_CAS(1, 3) RT_WIDE_CAS(1, 2)
+  if (t[3] < INF) trav_push(ts, c[3], stack, stride);
+  if (t[2] < INF) trav_push(ts, c[2], stack, stride);
+  if (t[1] < INF) trav_push(ts, c[1], stack, stride);
+  if (t[0] < INF) ts.cur = c[0];
+  else trav_pop(ts, stack, stride);
+}
+#undef RT_WIDE_CAS
 // precondition: ts.cur >= 0
 template <class Acc, class StackT>
 __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT* stack, int stride) {
+  if constexpr (Acc::kWide) {
+    node_step_wide(acc, ts, stack, stride);
+    return;
+  }
   float4 qx, qy, qz;
   int2 ch;
   acc.node_slabs(ts.cur, ts.s, qx, qy, qz, ch);

@@ -198,7 +198,7 @@ struct FusedParams {
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
 
-enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3 };
+enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5 };
 
 __device__ __forceinline__ unsigned long long to_fix(float v) {
   if (!(v > 0.f)) return 0ull;  // also NaN
@@ -230,6 +230,18 @@ template <> struct AccOf<KIND_SPHERES_GLOBAL> {
 template <> struct AccOf<KIND_GENERIC> {
   using type = GlobalAcc;
   static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) { return global_acc(sc); }
+};
+template <> struct AccOf<KIND_GENERIC_WIDE> {
+  using type = WideAcc<GlobalAcc>;
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) {
+    return type{global_acc(sc), sc.nodes4};
+  }
+};
+template <> struct AccOf<KIND_SPHERES_WIDE> {
+  using type = WideAcc<SphereAcc>;
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) {
+    return type{sphere_acc(sc), sc.nodes4};
+  }
 };
 
 // Register budget: 4 waves/SIMD (128 VGPRs) — what a 1024-thread workgroup needs anyway; the 256-thread instances that
@@ -494,6 +506,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
 
 struct rt_scene {
   BvhNode* d_nodes = nullptr;
+  float4* d_nodes4 = nullptr;  // four-wide form of the tree (HBM-resident fused instances)
+  int wide_stack = 0;          // stack entries a traversal of it needs
   Prim* d_prims = nullptr;
   Material* d_mats = nullptr;
   Texture* d_texs = nullptr;
@@ -524,6 +538,7 @@ struct rt_ctx {
   int fused_lds = 1;         // keep the scene in LDS when it fits
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
   int fused_kr = 16;
+  int fused_wide = 1;  // HBM-resident fused instances walk the four-wide tree
   int fused_resume = 2, fused_kb = 16, fused_kn = 8;  // 0 bounce-synchronous, 1 resumable traversals, 2 by scene size  // RESUME variant of k_fused + its thresholds    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
   float* d_dbg = nullptr;
   WorkBuffers wb;
@@ -685,6 +700,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_ku = (int)value;
   } else if (k == "fused_lds") {
     ctx->fused_lds = value ? 1 : 0;
+  } else if (k == "fused_wide") {
+    ctx->fused_wide = value ? 1 : 0;
   } else if (k == "fused_stats") {
     ctx->fused_stats = value ? 1 : 0;
   } else if (k == "fused_resume") {
@@ -733,6 +750,7 @@ int rt_scene_free(rt_ctx* ctx, rt_scene* s) {
   if (!s) return RT_OK;
   if (ctx) (void)hipSetDevice(ctx->device);
   if (s->d_nodes) (void)hipFree(s->d_nodes);
+  if (s->d_nodes4) (void)hipFree(s->d_nodes4);
   if (s->d_prims) (void)hipFree(s->d_prims);
   if (s->d_mats) (void)hipFree(s->d_mats);
   if (s->d_texs) (void)hipFree(s->d_texs);
@@ -917,6 +935,15 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   HIP_TRY(ctx, hipMalloc(&sc->d_nodes, n_nodes * sizeof(BvhNode)));
   if (!bvh.nodes.empty())
     HIP_TRY(ctx, hipMemcpy(sc->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+  {
+    static_assert(sizeof(rtb::WideNode) == 128, "wide node layout mismatch");
+    rtb::WideResult wide = rtb::collapse_bvh4(bvh);
+    sc->wide_stack = wide.stack_need;
+    if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] four-wide tree: %zu nodes, stack %d\n", wide.nodes.size(), wide.stack_need);
+    HIP_TRY(ctx, hipMalloc(&sc->d_nodes4, std::max<size_t>(wide.nodes.size(), 1) * sizeof(rtb::WideNode)));
+    if (!wide.nodes.empty())
+      HIP_TRY(ctx, hipMemcpy(sc->d_nodes4, wide.nodes.data(), wide.nodes.size() * sizeof(rtb::WideNode), hipMemcpyHostToDevice));
+  }
   HIP_TRY(ctx, hipMalloc(&sc->d_prims, prims.size() * sizeof(Prim)));
   HIP_TRY(ctx, hipMemcpy(sc->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
   HIP_TRY(ctx, hipMalloc(&sc->d_mats, mats.size() * sizeof(Material)));
@@ -943,6 +970,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   sc->view.spheres = sc->d_spheres;
   sc->view.bvh_depth = bvh.depth;
   sc->view.nodes = sc->d_nodes;
+  sc->view.nodes4 = sc->d_nodes4;
   sc->view.prims = sc->d_prims;
   sc->view.mats = sc->d_mats;
   sc->view.texs = sc->d_texs;
@@ -1253,14 +1281,23 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
     else rc = launch_variant<RT_F_ALL, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
   } else {
-    const size_t smem = 4 * 192 * 8 + (size_t)sdepth * 256 * 4;
-    if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_GLOBAL, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    else if (ctx->fused_stats) {
-      if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t, true, true>(ctx, scene, dc, fp, smem, st);
-      else rc = launch_fused<RT_F_ALL, KIND_GENERIC, 256, int32_t, true, false>(ctx, scene, dc, fp, smem, st);
-    } else rc = launch_variant<RT_F_ALL, KIND_GENERIC, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    // HBM-resident scene: four-wide tree by default (fused_wide = 0: the binary tree, kept as a cross-check)
+    const bool wide = ctx->fused_wide != 0;
+    const uint32_t sd = wide ? (uint32_t)scene->wide_stack + 2u : sdepth;
+    fp.stack_depth = sd;
+    const size_t smem = 4 * 192 * 8 + (size_t)sd * 256 * 4;
+    if (smem > 64 * 1024) return fail(ctx, RT_E_INTERNAL, "traversal stack does not fit in LDS");
+#define RT_GLOBAL_DISPATCH(KS, KG)                                                                                              \
+    if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KS, 256, int32_t>(ctx, scene, dc, fp, smem, st);       \
+    else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KS, 256, int32_t>(ctx, scene, dc, fp, smem, st);              \
+    else if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KG, 256, int32_t>(ctx, scene, dc, fp, smem, st);        \
+    else if (ctx->fused_stats) {                                                                                                \
+      if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KG, 256, int32_t, true, true>(ctx, scene, dc, fp, smem, st);      \
+      else rc = launch_fused<RT_F_ALL, KG, 256, int32_t, true, false>(ctx, scene, dc, fp, smem, st);                            \
+    } else rc = launch_variant<RT_F_ALL, KG, 256, int32_t>(ctx, scene, dc, fp, smem, st);
+    if (wide) { RT_GLOBAL_DISPATCH(KIND_SPHERES_WIDE, KIND_GENERIC_WIDE) }
+    else { RT_GLOBAL_DISPATCH(KIND_SPHERES_GLOBAL, KIND_GENERIC) }
+#undef RT_GLOBAL_DISPATCH
   }
   if (rc) return rc;
   tm.end(ctx->stats.ms_intersect);

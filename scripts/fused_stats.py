@@ -79,3 +79,7 @@ if "--grid5" in sys.argv:
 if "--lds" in sys.argv:  # LDS-resident vs HBM-resident instance on the chosen scene
     for v in (1, 0, 1, 0):
         run(False, fused_lds=v)
+if "--wide" in sys.argv:  # HBM-resident instances: four-wide tree vs binary tree
+    for v in (1, 0, 1, 0):
+        run(False, fused_wide=v)
+    run(True, fused_wide=1)

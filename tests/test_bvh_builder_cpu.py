@@ -25,6 +25,15 @@ def chk(tmp_path_factory):
         out = np.zeros(7, dtype=np.int64)
         assert lib.bvh_check(lohi.ctypes.data, len(lohi), max_depth, out.ctypes.data) == 0
         return dict(zip(["nodes", "depth", "leaves", "wrong", "bad_box", "root", "max_stack"], out.tolist()))
+    lib.bvh4_check.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+
+    def run4(lohi, max_depth=32):
+        lohi = np.ascontiguousarray(lohi, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros(8, dtype=np.int64)
+        assert lib.bvh4_check(lohi.ctypes.data, len(lohi), max_depth, out.ctypes.data) == 0
+        return dict(zip(["nodes", "stack_need", "leaves", "wrong", "bad_box", "max_pending", "bad_empty", "fill_x1000"],
+                        out.tolist()))
+    run.wide = run4
     return run
 
 
@@ -77,3 +86,27 @@ def test_large_coordinates_stay_conservative_in_f32(chk):
     boxes = sphere_boxes(c, rng.uniform(0.01, 1e6, 300))
     r = chk(boxes)
     assert r["leaves"] == 300 and r["wrong"] == 0 and r["bad_box"] == 0
+
+
+def test_four_wide_collapse(chk):
+    """rt_bvh.cpp collapse_bvh4: what the HBM-resident fused instances traverse."""
+    rng = np.random.default_rng(3)
+    a, b = np.meshgrid(np.arange(-11, 11), np.arange(-11, 11))
+    c = np.stack([a.ravel() + 0.9 * rng.random(484), np.full(484, 0.2), b.ravel() + 0.9 * rng.random(484)], axis=1)
+    field = np.vstack([sphere_boxes(c, np.full(484, 0.2)), sphere_boxes([[0, -1000, 0]], [1000])])
+    cloud = sphere_boxes(rng.uniform(-100, 100, (3000, 3)), rng.uniform(0.1, 10, 3000))
+    quads = np.array([[0, 0, i, 1, 1, i] for i in range(33)], float)
+    for boxes in (field, cloud, quads, sphere_boxes([[0, 0, 0], [5, 0, 0]], [1, 1]), sphere_boxes(np.zeros((3, 3)), [1, 2, 3])):
+        r2, r = chk(boxes), chk.wide(boxes)
+        assert r["leaves"] == len(boxes) and r["wrong"] == 0 and r["bad_box"] == 0 and r["bad_empty"] == 0
+        assert r["nodes"] <= r2["nodes"] and r["max_pending"] <= r["stack_need"] <= 3 * r2["depth"]
+        if len(boxes) > 100:
+            # one primitive per leaf: the bottom level's nodes hold 2..4 leaves, 3 on average
+            assert r["fill_x1000"] > 2900 and r["nodes"] < 0.55 * r2["nodes"]
+    r = chk.wide(sphere_boxes([[1, 2, 3]], [0.5]))  # a lone primitive stays the root leaf: nothing to collapse
+    assert r["nodes"] == 0 and r["leaves"] == 1 and r["wrong"] == 0
+    # adversarial chain (one primitive peeled per level): the stack bound still holds under the depth cap
+    n = 200
+    cc = np.stack([2.0 ** np.arange(n) * 1e-20, np.zeros(n), np.zeros(n)], axis=1)
+    r = chk.wide(sphere_boxes(cc, 2.0 ** np.arange(n) * 0.4e-20), max_depth=16)
+    assert r["leaves"] == n and r["wrong"] == 0 and r["bad_box"] == 0 and r["max_pending"] <= r["stack_need"] <= 48
