@@ -239,6 +239,24 @@ WideResult collapse_bvh4(const BuildResult& bvh) {
   if (bvh.root < 0) return out;  // empty scene or a single primitive: nothing to collapse
   out.nodes.reserve(bvh.nodes.size() / 2 + 1);
   collapse_rec(bvh, bvh.root, out, out.stack_need);
+  // Renumber breadth-first: node indices grow with depth, so "index < n" selects the top of the tree (the part the
+  // fused kernel keeps in LDS) and siblings share cache lines' neighbourhoods.
+  std::vector<int32_t> order, new_of(out.nodes.size(), -1);
+  order.reserve(out.nodes.size());
+  order.push_back(0);
+  for (size_t head = 0; head < order.size(); head++)
+    for (int k = 0; k < 4; k++) {
+      const int32_t c = out.nodes[(size_t)order[head]].child[k];
+      if (c >= 0) order.push_back(c);
+    }
+  for (size_t i = 0; i < order.size(); i++) new_of[(size_t)order[i]] = (int32_t)i;
+  std::vector<WideNode> sorted(order.size());
+  for (size_t i = 0; i < order.size(); i++) {
+    sorted[i] = out.nodes[(size_t)order[i]];
+    for (int k = 0; k < 4; k++)
+      if (sorted[i].child[k] >= 0) sorted[i].child[k] = new_of[(size_t)sorted[i].child[k]];
+  }
+  out.nodes.swap(sorted);
   return out;
 }
 

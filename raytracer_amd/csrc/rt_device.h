@@ -66,6 +66,8 @@ struct Scene {
   const uint32_t* texels;    // RGBA8
   const uint4* noise_table;  // 16 x 256 x 128-bit GF(2) table of the xoroshiro short jump
   const float4* nodes4;      // four-wide form of the tree (128-B nodes, see WideAcc), root = node 0
+  const uint4* nodes4h;      // the same with binary16 planes rounded outward (64-B nodes, see WideHalfAcc)
+  int32_t n_nodes4;
   int32_t n_nodes, n_prims, n_mats, n_texs;
   int32_t root;  // >=0 node, <0 single leaf
   int32_t bvh_depth;
@@ -349,6 +351,45 @@ struct WideAcc : Base {
   const float4* nodes4;
   static constexpr bool kWide = true;
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? 0 : r; }
+  // entry (e*) / exit (f*) planes of the four children for the ray's direction, by select
+  __device__ __forceinline__ void wide_node(int32_t i, const SlabRay& s, float4& ex, float4& fx, float4& ey, float4& fy,
+                                            float4& ez, float4& fz, int4& ch) const {
+    const float4* np = nodes4 + 8 * (size_t)i;
+    const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
+    ch = *reinterpret_cast<const int4*>(np + 6);
+    ex = s.sx ? hix : lox; fx = s.sx ? lox : hix;
+    ey = s.sy ? hiy : loy; fy = s.sy ? loy : hiy;
+    ez = s.sz ? hiz : loz; fz = s.sz ? loz : hiz;
+  }
+};
+// Four-wide tree with binary16 planes, rounded outward when the scene is uploaded: 64-B nodes
+// [lo.x[4] hi.x[4]] [lo.y[4] hi.y[4]] [lo.z[4] hi.z[4]] child[4] — four 16-byte fetches per step instead of seven
+// (the HBM-resident instances are bound by the bytes their node fetches pull through the vector cache, DESIGN.md
+// section 7).  Nodes are numbered breadth-first and every workgroup copies the first n_cached of them — the top of
+// the tree, or all of it — into LDS; a lane's node pointer is then an LDS or a global address and the fetch is a
+// FLAT load that the hardware routes per lane.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 half4_to_float4(uint32_t a, uint32_t b) {
+  const h16x2 p = __builtin_bit_cast(h16x2, a), q = __builtin_bit_cast(h16x2, b);
+  return float4{(float)p.x, (float)p.y, (float)q.x, (float)q.y};
+}
+template <class Base>
+struct WideHalfAcc : Base {
+  const uint4* nodes4h;
+  const uint4* cache;  // generic pointer into LDS
+  int32_t n_cached;
+  static constexpr bool kWide = true;
+  __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? 0 : r; }
+  __device__ __forceinline__ void wide_node(int32_t i, const SlabRay& s, float4& ex, float4& fx, float4& ey, float4& fy,
+                                            float4& ez, float4& fz, int4& ch) const {
+    const uint4* np = (i < n_cached ? cache : nodes4h) + 4 * (size_t)i;
+    const uint4 ax = np[0], ay = np[1], az = np[2];
+    const uint4 l = np[3];
+    ch = int4{(int32_t)l.x, (int32_t)l.y, (int32_t)l.z, (int32_t)l.w};
+    ex = half4_to_float4(s.sx ? ax.z : ax.x, s.sx ? ax.w : ax.y); fx = half4_to_float4(s.sx ? ax.x : ax.z, s.sx ? ax.y : ax.w);
+    ey = half4_to_float4(s.sy ? ay.z : ay.x, s.sy ? ay.w : ay.y); fy = half4_to_float4(s.sy ? ay.x : ay.z, s.sy ? ay.y : ay.w);
+    ez = half4_to_float4(s.sz ? az.z : az.x, s.sz ? az.w : az.y); fz = half4_to_float4(s.sz ? az.x : az.z, s.sz ? az.y : az.w);
+  }
 };
 __device__ __forceinline__ void slab_node_store(unsigned char* l_nodes, int i, const BvhNode& n) {
   float4* w = reinterpret_cast<float4*>(l_nodes + (size_t)i * RT_SLAB_NODE_BYTES);
@@ -534,24 +575,15 @@ __device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int strid
   ts.sp = max(ts.sp - 1, 0);
 }
 // One step through a four-wide node: test the four boxes, continue with the nearest one hit and push the others
-// farthest first.  Unused slots never hit (child == RT_EMPTY_CHILD).
-#define RT_WIDE_CAS(i, j)                                  \
-  {                                                        \
-    const bool sw = t[j] < t[i];                           \
-    const float ti = t[i], tj = t[j];                      \
-    const int32_t ci = c[i], cj = c[j];                    \
-    t[i] = sw ? tj : ti; t[j] = sw ? ti : tj;              \
-    c[i] = sw ? cj : ci; c[j] = sw ? ci : cj;              \
-  }
+// farthest first (5-exchange sorting network on (entry distance, link) pairs).  Unused slots carry an inverted
+// (+inf, -inf) box, which no ray with a finite non-zero direction component enters, and a copy of slot 0's link, so
+// that even a degenerate ray only repeats work: the step has no test for them.
 template <class Acc, class StackT>
 __device__ __forceinline__ void node_step_wide(const Acc& acc, TravState& ts, StackT* stack, int stride) {
-  const float4* np = acc.nodes4 + 8 * (size_t)ts.cur;
-  const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5];
-  const int4 ch = *reinterpret_cast<const int4*>(np + 6);
   const SlabRay& s = ts.s;
-  const float4 ex = s.sx ? hix : lox, fx = s.sx ? lox : hix;  // entry / exit planes for the ray's direction
-  const float4 ey = s.sy ? hiy : loy, fy = s.sy ? loy : hiy;
-  const float4 ez = s.sz ? hiz : loz, fz = s.sz ? loz : hiz;
+  float4 ex, fx, ey, fy, ez, fz;  // entry / exit planes for the ray's direction
+  int4 ch;
+  acc.wide_node(ts.cur, s, ex, fx, ey, fy, ez, fz, ch);
   const float INF = __builtin_inff();
   float t[4];
   int32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
@@ -561,36 +593,44 @@ __device__ __forceinline__ void node_step_wide(const Acc& acc, TravState& ts, St
                                  __builtin_fmaf(ez.m, s.iz, -s.nz)), 0.f);                                          \
     const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, s.ixw, -s.fx), __builtin_fmaf(fy.m, s.iyw, -s.fy)),     \
                                  __builtin_fmaf(fz.m, s.izw, -s.fz)), ts.tmax_w);                                   \
-    t[k] = (tn <= tf && c[k] != RT_EMPTY_CHILD) ? tn : INF;                                                         \
+    t[k] = tn <= tf ? tn : INF;                                                                                     \
   }
   RT_WIDE_SLOT(0, x) RT_WIDE_SLOT(1, y) RT_WIDE_SLOT(2, z) RT_WIDE_SLOT(3, w)
 #undef RT_WIDE_SLOT
+#define RT_WIDE_CAS(i, j)                                  \
+  {                                                        \
+    const bool sw = t[j] < t[i];                           \
+    const float ti = t[i], tj = t[j];                      \
+    const int32_t ci = c[i], cj = c[j];                    \
+    t[i] = sw ? tj : ti; t[j] = sw ? ti : tj;              \
+    c[i] = sw ? cj : ci; c[j] = sw ? ci : cj;              \
+  }
   RT_WIDE_CAS(0, 1) RT_WIDE_CAS(2, 3) RT_WIDE_CAS(0, 2) RT_WIDE_CAS(1, 3) RT_WIDE_CAS(1, 2)
+#undef RT_WIDE_CAS
   if (t[3] < INF) trav_push(ts, c[3], stack, stride);
   if (t[2] < INF) trav_push(ts, c[2], stack, stride);
   if (t[1] < INF) trav_push(ts, c[1], stack, stride);
   if (t[0] < INF) ts.cur = c[0];
   else trav_pop(ts, stack, stride);
 }
-#undef RT_WIDE_CAS
 // precondition: ts.cur >= 0
 template <class Acc, class StackT>
 __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT* stack, int stride) {
   if constexpr (Acc::kWide) {
     node_step_wide(acc, ts, stack, stride);
-    return;
+  } else {
+    float4 qx, qy, qz;
+    int2 ch;
+    acc.node_slabs(ts.cur, ts.s, qx, qy, qz, ch);
+    float tl, tr;
+    bool hl, hr;
+    slab_pair_test(ts.s, qx, qy, qz, ts.tmax_w, tl, tr, hl, hr);
+    const bool left_first = tl <= tr;
+    const bool take_left = hl && (!hr || left_first);
+    if (hl && hr) trav_push(ts, left_first ? ch.y : ch.x, stack, stride);
+    if (hl || hr) ts.cur = take_left ? ch.x : ch.y;
+    else trav_pop(ts, stack, stride);
   }
-  float4 qx, qy, qz;
-  int2 ch;
-  acc.node_slabs(ts.cur, ts.s, qx, qy, qz, ch);
-  float tl, tr;
-  bool hl, hr;
-  slab_pair_test(ts.s, qx, qy, qz, ts.tmax_w, tl, tr, hl, hr);
-  const bool left_first = tl <= tr;
-  const bool take_left = hl && (!hr || left_first);
-  if (hl && hr) trav_push(ts, left_first ? ch.y : ch.x, stack, stride);
-  if (hl || hr) ts.cur = take_left ? ch.x : ch.y;
-  else trav_pop(ts, stack, stride);
 }
 // precondition: ts.cur < 0 && ts.cur != RT_DONE
 template <class Acc, class StackT>

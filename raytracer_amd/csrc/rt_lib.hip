@@ -195,10 +195,14 @@ struct FusedParams {
   uint32_t kb, kn;  // RESUME variant: hand-back / node-loop exit thresholds (traverse_resume)
   uint32_t noise_lds;  // the LDS-resident instances copy the noise jump table into LDS (scene has a noise texture)
   uint32_t kr;      // regenerate only when at least kr lanes are free (or none carries a path)
+  uint32_t n_cached;  // four-wide nodes each workgroup copies into LDS (KIND_*_WIDE_HALF)
 };
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
 
-enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5 };
+enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5,
+       KIND_GENERIC_WIDE_HALF = 6, KIND_SPHERES_WIDE_HALF = 7 };
+constexpr bool kind_caches_top(int k) { return k == KIND_GENERIC_WIDE_HALF || k == KIND_SPHERES_WIDE_HALF; }
+constexpr bool kind_in_lds(int k) { return k == KIND_SPHERES_LDS || k == KIND_GENERIC_LDS; }
 
 __device__ __forceinline__ unsigned long long to_fix(float v) {
   if (!(v > 0.f)) return 0ull;  // also NaN
@@ -237,6 +241,18 @@ template <> struct AccOf<KIND_GENERIC_WIDE> {
     return type{global_acc(sc), sc.nodes4};
   }
 };
+template <> struct AccOf<KIND_GENERIC_WIDE_HALF> {
+  using type = WideHalfAcc<GlobalAcc>;
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char* ln, const SphereRec*, LdsTablePtr) {
+    return type{global_acc(sc), sc.nodes4h, reinterpret_cast<const uint4*>(ln), 0};  // n_cached: set by k_fused
+  }
+};
+template <> struct AccOf<KIND_SPHERES_WIDE_HALF> {
+  using type = WideHalfAcc<SphereAcc>;
+  static __device__ __forceinline__ type make(const Scene& sc, const unsigned char* ln, const SphereRec*, LdsTablePtr) {
+    return type{sphere_acc(sc), sc.nodes4h, reinterpret_cast<const uint4*>(ln), 0};
+  }
+};
 template <> struct AccOf<KIND_SPHERES_WIDE> {
   using type = WideAcc<SphereAcc>;
   static __device__ __forceinline__ type make(const Scene& sc, const unsigned char*, const SphereRec*, LdsTablePtr) {
@@ -248,7 +264,7 @@ template <> struct AccOf<KIND_SPHERES_WIDE> {
 // carry the noise / image / medium code (HBM-resident scenes: C5) run better at 3 waves/SIMD with 168 VGPRs and
 // 272 B of scratch than at 4 with 432 B (26.4 vs 32.6 ms on C5 at 4 spp; 2 waves / 243 VGPRs / no scratch: 30.9).
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 : 4) void k_fused(Scene sc, const Camera* __restrict__ camp, FusedParams fp, uint32_t* __restrict__ unit_counter,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_TEX_NOISE))) ? 3 : 4) void k_fused(Scene sc, const Camera* __restrict__ camp, FusedParams fp, uint32_t* __restrict__ unit_counter,
                                                  unsigned long long* __restrict__ fbacc,
                                                  unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
   // The camera block (26 doubles) stays in memory: read with scalar loads where a ray is generated instead of
@@ -264,13 +280,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
   LdsTablePtr l_noise = nullptr;
-  if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) {
+  if (kind_in_lds(KIND)) {
     off += RT_SLAB_REGION_BYTES(sc.n_nodes);
     l_sph = reinterpret_cast<SphereRec*>(smem + off);
-    const int rec16 = KIND == KIND_SPHERES_LDS ? 4 : 8;  // record size in float4s: SphereRec 64 B / Prim 128 B
+    const int rec16 = KIND != KIND_GENERIC_LDS ? 4 : 8;  // record size in float4s: SphereRec 64 B / Prim 128 B
     off += (size_t)sc.n_prims * rec16 * 16;
     for (int i = threadIdx.x; i < sc.n_nodes; i += BLOCK) slab_node_store(l_nodes, i, sc.nodes[i]);
-    const float4* gs = KIND == KIND_SPHERES_LDS ? reinterpret_cast<const float4*>(sc.spheres)
+    const float4* gs = KIND != KIND_GENERIC_LDS ? reinterpret_cast<const float4*>(sc.spheres)
                                                 : reinterpret_cast<const float4*>(sc.prims);
     float4* ls = reinterpret_cast<float4*>(l_sph);
     for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
@@ -281,11 +297,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && (F & RT_F_TEX_NOISE)) ? 3 :
       for (int i = threadIdx.x; i < 16 * 256; i += BLOCK) lt[i] = sc.noise_table[i];
     }
   }
+  if (kind_caches_top(KIND)) {
+    off += (size_t)fp.n_cached * 64;
+    uint4* lc = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < fp.n_cached * 4u; i += BLOCK) lc[i] = sc.nodes4h[i];
+  }
   unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
   off += (size_t)(BLOCK / 64) * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
-  if (KIND == KIND_SPHERES_LDS || KIND == KIND_GENERIC_LDS) __syncthreads();
-  const typename AccOf<KIND>::type acc = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
+  if (kind_in_lds(KIND) || kind_caches_top(KIND)) __syncthreads();
+  typename AccOf<KIND>::type acc_init = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
+  if constexpr (kind_caches_top(KIND)) acc_init.n_cached = (int32_t)fp.n_cached;
+  const typename AccOf<KIND>::type acc = acc_init;
 
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long my_rays = 0;
@@ -507,6 +530,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
 struct rt_scene {
   BvhNode* d_nodes = nullptr;
   float4* d_nodes4 = nullptr;  // four-wide form of the tree (HBM-resident fused instances)
+  uint4* d_nodes4h = nullptr;  // ... with binary16 planes
+  bool half_ok = false;        // every finite plane is inside the binary16 range
   int wide_stack = 0;          // stack entries a traversal of it needs
   Prim* d_prims = nullptr;
   Material* d_mats = nullptr;
@@ -539,6 +564,7 @@ struct rt_ctx {
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
   int fused_kr = 16;
   int fused_wide = 1;  // HBM-resident fused instances walk the four-wide tree
+  int fused_half = 1;  // ... in its binary16 form, top levels cached in LDS, when the scene allows
   int fused_resume = 2, fused_kb = 16, fused_kn = 8;  // 0 bounce-synchronous, 1 resumable traversals, 2 by scene size  // RESUME variant of k_fused + its thresholds    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
   float* d_dbg = nullptr;
   WorkBuffers wb;
@@ -700,6 +726,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_ku = (int)value;
   } else if (k == "fused_lds") {
     ctx->fused_lds = value ? 1 : 0;
+  } else if (k == "fused_half") {
+    ctx->fused_half = value ? 1 : 0;
   } else if (k == "fused_wide") {
     ctx->fused_wide = value ? 1 : 0;
   } else if (k == "fused_stats") {
@@ -717,6 +745,21 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
 }
 
 // ------------------------------------------------------------------------------------------------ scene upload
+// binary16 bits of x rounded towards +inf (up) or -inf: the nearest value, stepped once if it lies on the wrong side
+static uint16_t half_round(float x, bool up) {
+  _Float16 h = (_Float16)x;
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  const float back = (float)h;
+  if (std::isnan(x)) return b;
+  if (up ? back < x : back > x) {
+    const bool neg = b & 0x8000u;
+    if ((b & 0x7FFFu) == 0) b = up ? 0x0001u : 0x8001u;  // from +-0 to the smallest denormal of the wanted sign
+    else if (up != neg) b++;                            // away from zero
+    else b--;                                          // towards zero
+  }
+  return b;
+}
 static bool finite3(const double* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
 
 static int validate_texture_graph(rt_ctx* ctx, const rt_scene_desc* d) {
@@ -751,6 +794,7 @@ int rt_scene_free(rt_ctx* ctx, rt_scene* s) {
   if (ctx) (void)hipSetDevice(ctx->device);
   if (s->d_nodes) (void)hipFree(s->d_nodes);
   if (s->d_nodes4) (void)hipFree(s->d_nodes4);
+  if (s->d_nodes4h) (void)hipFree(s->d_nodes4h);
   if (s->d_prims) (void)hipFree(s->d_prims);
   if (s->d_mats) (void)hipFree(s->d_mats);
   if (s->d_texs) (void)hipFree(s->d_texs);
@@ -939,7 +983,33 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     static_assert(sizeof(rtb::WideNode) == 128, "wide node layout mismatch");
     rtb::WideResult wide = rtb::collapse_bvh4(bvh);
     sc->wide_stack = wide.stack_need;
+    sc->view.n_nodes4 = (int32_t)wide.nodes.size();
+    // the device never tests for unused slots: their inverted boxes cannot be entered, and their links repeat slot 0's
+    for (rtb::WideNode& w : wide.nodes)
+      for (int k = 1; k < 4; k++)
+        if (w.child[k] == rtb::EMPTY_CHILD) w.child[k] = w.child[0];
     if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] four-wide tree: %zu nodes, stack %d\n", wide.nodes.size(), wide.stack_need);
+    {
+      struct HalfNode { uint16_t p[3][8]; int32_t child[4]; };
+      static_assert(sizeof(HalfNode) == 64, "half node layout mismatch");
+      std::vector<HalfNode> hn(std::max<size_t>(wide.nodes.size(), 1));
+      memset(hn.data(), 0, hn.size() * sizeof(HalfNode));
+      sc->half_ok = !wide.nodes.empty();
+      for (size_t i = 0; i < wide.nodes.size(); i++)
+        for (int k = 0; k < 4; k++) {
+          for (int a = 0; a < 3; a++) {
+            // beyond the binary16 range a plane would round to infinity: still conservative, but it culls nothing
+            const float lo = wide.nodes[i].lo[a][k], hi = wide.nodes[i].hi[a][k];
+            if (lo <= hi && (std::fabs(lo) > 60000.f || std::fabs(hi) > 60000.f)) sc->half_ok = false;
+            hn[i].p[a][k] = half_round(wide.nodes[i].lo[a][k], false);
+            hn[i].p[a][4 + k] = half_round(wide.nodes[i].hi[a][k], true);
+          }
+          hn[i].child[k] = wide.nodes[i].child[k];
+        }
+      HIP_TRY(ctx, hipMalloc(&sc->d_nodes4h, hn.size() * sizeof(HalfNode)));
+      HIP_TRY(ctx, hipMemcpy(sc->d_nodes4h, hn.data(), hn.size() * sizeof(HalfNode), hipMemcpyHostToDevice));
+      sc->view.nodes4h = sc->d_nodes4h;
+    }
     HIP_TRY(ctx, hipMalloc(&sc->d_nodes4, std::max<size_t>(wide.nodes.size(), 1) * sizeof(rtb::WideNode)));
     if (!wide.nodes.empty())
       HIP_TRY(ctx, hipMemcpy(sc->d_nodes4, wide.nodes.data(), wide.nodes.size() * sizeof(rtb::WideNode), hipMemcpyHostToDevice));
@@ -1295,7 +1365,23 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
       if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KG, 256, int32_t, true, true>(ctx, scene, dc, fp, smem, st);      \
       else rc = launch_fused<RT_F_ALL, KG, 256, int32_t, true, false>(ctx, scene, dc, fp, smem, st);                            \
     } else rc = launch_variant<RT_F_ALL, KG, 256, int32_t>(ctx, scene, dc, fp, smem, st);
-    if (wide) { RT_GLOBAL_DISPATCH(KIND_SPHERES_WIDE, KIND_GENERIC_WIDE) }
+    // Preferred form: binary16 planes, one workgroup per CU with the top of the tree (or all of it) in LDS — when the
+    // scene's coordinates fit binary16 and its references the 16-bit stack.  768 threads (3 waves/SIMD, 168 VGPRs)
+    // for the instances with the noise code, 1024 otherwise.
+    const bool heavy = !(scene->spheres_only && lean);  // instances compiled with RT_F_TEX_NOISE
+    const uint32_t cblock = heavy ? 768u : 1024u;
+    const size_t cfixed = (size_t)(cblock / 64) * 192 * 8 + (size_t)sd * cblock * 2;
+    const bool ids16 = scene->view.n_nodes4 < 32768 && scene->view.n_prims < 32768;
+    if (wide && ctx->fused_half && scene->half_ok && ids16 && cfixed + 16 * 64 <= 160 * 1024) {
+      fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (160 * 1024 - cfixed) / 64);
+      const size_t csmem = cfixed + (size_t)fp.n_cached * 64;
+      if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 1024, int16_t>(ctx, scene, dc, fp, csmem, st);
+      else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_WIDE_HALF, 768, int16_t>(ctx, scene, dc, fp, csmem, st);
+      else if (ctx->fused_stats) {
+        if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, 768, int16_t, true, true>(ctx, scene, dc, fp, csmem, st);
+        else rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, 768, int16_t, true, false>(ctx, scene, dc, fp, csmem, st);
+      } else rc = launch_variant<RT_F_ALL, KIND_GENERIC_WIDE_HALF, 768, int16_t>(ctx, scene, dc, fp, csmem, st);
+    } else if (wide) { RT_GLOBAL_DISPATCH(KIND_SPHERES_WIDE, KIND_GENERIC_WIDE) }
     else { RT_GLOBAL_DISPATCH(KIND_SPHERES_GLOBAL, KIND_GENERIC) }
 #undef RT_GLOBAL_DISPATCH
   }

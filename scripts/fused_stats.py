@@ -83,3 +83,7 @@ if "--wide" in sys.argv:  # HBM-resident instances: four-wide tree vs binary tre
     for v in (1, 0, 1, 0):
         run(False, fused_wide=v)
     run(True, fused_wide=1)
+if "--half" in sys.argv:  # HBM-resident instances: binary16 planes + LDS cache of the top vs f32 four-wide tree
+    for h in (1, 0, 1, 0):
+        run(False, fused_half=h)
+    run(True, fused_half=1)

@@ -63,16 +63,19 @@ def test_c2_workload_statistics_match_the_oracle_fixture(ctx, c2):
 def test_c2_kernel_variants_agree_at_full_size(ctx, c2):
     host, dev, cam = c2
     a = dev.render_sums(cam, seed=3).astype(np.float64)
-    ctx.set_option("fused_lds", 0)  # scene from HBM/L2, 64-B nodes, select-based slab fetch, 256-thread blocks
+    ctx.set_option("fused_lds", 0)  # scene from HBM/L2: four-wide tree, binary16 planes, top levels cached in LDS
     try:
         b = dev.render_sums(cam, seed=3).astype(np.float64)
-        ctx.set_option("fused_wide", 0)  # the same from the binary tree instead of the four-wide one
+        ctx.set_option("fused_half", 0)  # four-wide tree with f32 planes, 256-thread blocks, no LDS cache
         c = dev.render_sums(cam, seed=3).astype(np.float64)
+        ctx.set_option("fused_wide", 0)  # binary tree (64-B nodes)
+        d = dev.render_sums(cam, seed=3).astype(np.float64)
     finally:
         ctx.set_option("fused_lds", 1)
+        ctx.set_option("fused_half", 1)
         ctx.set_option("fused_wide", 1)
     # same paths, separately compiled code (FMA contraction in the f32 shading differs): a handful of paths flip
-    for other in (b, c):
+    for other in (b, c, d):
         close = np.isclose(a, other, rtol=1e-4, atol=1e-3).all(axis=2).mean()
         assert close > 0.98 and abs(a.sum() - other.sum()) < 2e-4 * a.sum()
 
