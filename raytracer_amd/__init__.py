@@ -134,12 +134,25 @@ def hostlib():
     H.rth_scene_render_partial.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]
     H.rth_scene_render_progressive.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_char_p, C.c_char_p, vp, vp,
                                                C.POINTER(C.c_uint64)]
+    H.rth_write_image.argtypes = [C.c_char_p, vp, C.c_uint64, C.c_uint64]
     H.rth_rng_next_f64_seq.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp, vp]
     _host = H
     return H
 
 
 TILE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_double))
+
+
+def write_image(path, rgb):
+    """Writes an (H, W, 3) array of gamma-corrected colours with the host layer's writer: the reference's plain-text
+    PPM (camera/mod.rs:216-227), or PNG when `path` ends in ".png".  Needs no GPU."""
+    import numpy as np
+    a = np.ascontiguousarray(rgb, dtype=np.float64)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("rgb must have shape (H, W, 3)")
+    H = hostlib()
+    if H.rth_write_image(str(path).encode(), a.ctypes.data, a.shape[1], a.shape[0]) != 0:
+        raise RuntimeError(H.rth_last_error().decode())
 
 
 def philox4x32_10(ctr, key):

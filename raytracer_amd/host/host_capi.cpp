@@ -156,4 +156,22 @@ void rth_rng_next_f64_seq(uint64_t a, uint64_t b, int short_jumps, int n, double
   for (int i = 0; i < n; i++) out[i] = r.next_f64();
 }
 
+// Writes W x H gamma-corrected colours (row-major, 3 f64 each: what the tile messages carry) with the camera's
+// writer: plain-text PPM as in the reference, or PNG when the path ends in ".png".  Needs no GPU.
+int rth_write_image(const char* path, const double* rgb, uint64_t width, uint64_t height) {
+  try {
+    if (!path || !rgb) throw Error("rth_write_image: NULL argument");
+    std::vector<Color> buf((size_t)(width * height));
+    for (size_t i = 0; i < buf.size(); i++) buf[i] = Color(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+    Camera::write_buffer_to_file(path, buf, (size_t)width, (size_t)height);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  } catch (...) {
+    g_err = "unknown exception";
+    return -1;
+  }
+}
+
 }  // extern "C"

@@ -499,8 +499,86 @@ size_t Camera::render_progressive(const Hittable& world, const TileSender& sende
   return rendered;
 }
 
+// ---- PNG (8-bit RGB, no filtering, deflate "stored" blocks: no compression library needed; RFC 1950/1951/2083)
+namespace {
+uint32_t crc32_update(uint32_t c, const uint8_t* p, size_t n) {
+  static uint32_t table[256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t v = i;
+      for (int k = 0; k < 8; k++) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+      table[i] = v;
+    }
+    ready = true;
+  }
+  for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+  return c;
+}
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+  for (int k = 3; k >= 0; k--) v.push_back((uint8_t)(x >> (8 * k)));
+}
+void png_chunk(FILE* f, const char type[4], const std::vector<uint8_t>& data) {
+  std::vector<uint8_t> head;
+  put_be32(head, (uint32_t)data.size());
+  head.insert(head.end(), type, type + 4);
+  uint32_t crc = crc32_update(0xFFFFFFFFu, head.data() + 4, 4);
+  crc = crc32_update(crc, data.data(), data.size()) ^ 0xFFFFFFFFu;
+  std::vector<uint8_t> tail;
+  put_be32(tail, crc);
+  std::fwrite(head.data(), 1, head.size(), f);
+  if (!data.empty()) std::fwrite(data.data(), 1, data.size(), f);
+  std::fwrite(tail.data(), 1, tail.size(), f);
+}
+void write_png(const std::string& path, const std::vector<Color>& image_buffer, size_t width, size_t height) {
+  if (width == 0 || height == 0 || width > 0x7FFFFFFFu || height > 0x7FFFFFFFu) throw Error("png: bad image size");
+  std::vector<uint8_t> raw;  // scanlines, each prefixed with filter type 0
+  raw.reserve(height * (1 + 3 * width));
+  for (size_t j = 0; j < height; j++) {
+    raw.push_back(0);
+    for (size_t i = 0; i < width; i++) {
+      auto [r, g, b] = image_buffer[j * width + i].into_u8();
+      raw.push_back(r); raw.push_back(g); raw.push_back(b);
+    }
+  }
+  std::vector<uint8_t> z = {0x78, 0x01};  // zlib header: deflate, 32 K window, no preset dictionary
+  uint32_t s1 = 1, s2 = 0;                // Adler-32 of the raw data
+  for (size_t off = 0; off < raw.size();) {
+    const size_t n = std::min<size_t>(65535, raw.size() - off);
+    z.push_back(off + n == raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+    z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+    z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+    z.insert(z.end(), raw.begin() + (ptrdiff_t)off, raw.begin() + (ptrdiff_t)(off + n));
+    for (size_t i = off; i < off + n; i++) { s1 = (s1 + raw[i]) % 65521u; s2 = (s2 + s1) % 65521u; }
+    off += n;
+  }
+  put_be32(z, (s2 << 16) | s1);
+  FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) throw Error("cannot create " + path);
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::fwrite(sig, 1, 8, f);
+  std::vector<uint8_t> ihdr;
+  put_be32(ihdr, (uint32_t)width);
+  put_be32(ihdr, (uint32_t)height);
+  ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});  // 8 bits per channel, colour type 2 (RGB), deflate, no filter, no interlace
+  png_chunk(f, "IHDR", ihdr);
+  png_chunk(f, "IDAT", z);
+  png_chunk(f, "IEND", {});
+  const bool bad = std::ferror(f) != 0;
+  if (std::fclose(f) != 0 || bad) throw Error("write failed: " + path);
+}
+bool ends_with(const std::string& s, const char* suffix) {
+  const size_t n = std::strlen(suffix);
+  return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+}  // namespace
+
+// The reference writes plain-text PPM (mod.rs:216-227, color.rs:74-81); a path ending in ".png" selects PNG with
+// the same 8-bit quantisation.
 void Camera::write_buffer_to_file(const std::string& path, const std::vector<Color>& image_buffer, size_t width,
-                                  size_t height) {  // mod.rs:216-227, color.rs:74-81
+                                  size_t height) {
+  if (image_buffer.size() != width * height) throw Error("write_buffer_to_file: buffer does not match the image size");
+  if (ends_with(path, ".png") || ends_with(path, ".PNG")) return write_png(path, image_buffer, width, height);
   FILE* f = std::fopen(path.c_str(), "w");
   if (!f) throw Error("cannot create " + path);
   std::fprintf(f, "P3\n%zu %zu\n255\n", width, height);

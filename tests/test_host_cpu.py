@@ -193,3 +193,39 @@ def test_cpp_example_is_built_and_fails_cleanly_without_a_gpu():
         pytest.skip("GPU present (the GPU run is tests/test_gpu_example.py)")
     r = subprocess.run([exe, "two_spheres", "64", "4", "4", "/dev/null"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_image_writers_ppm_and_png(tmp_path):
+    """Output path: the reference's P3 text PPM (camera/mod.rs:216-227, color.rs:68-81) and the PNG
+    variant carry the same saturating 8-bit quantisation; the PNG is read back with an independent decoder."""
+    import zlib
+    import struct
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-0.2, 1.3, (37, 301, 3))  # odd sizes; values outside [0, 1] saturate; > 65535 B of scanlines
+    ra.write_image(tmp_path / "a.ppm", img)
+    ra.write_image(tmp_path / "a.png", img)
+    tok = (tmp_path / "a.ppm").read_text().split()
+    assert tok[:4] == ["P3", "301", "37", "255"]
+    ppm = np.array(tok[4:], dtype=np.int64).reshape(37, 301, 3)
+    want = np.clip(img * 256.0, 0, 255).astype(np.int64)  # `as u8` of a float saturates and truncates
+    assert np.array_equal(ppm, want)
+    raw = (tmp_path / "a.png").read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (301, 37, 8, 2, 0, 0, 0)
+    lines = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(37, 1 + 3 * 301)  # checks Adler-32 too
+    assert (lines[:, 0] == 0).all() and np.array_equal(lines[:, 1:].reshape(37, 301, 3), want)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "a.png").convert("RGB")), want)
+    with pytest.raises(RuntimeError):
+        ra.write_image(tmp_path / "no_such_dir" / "a.png", img)
