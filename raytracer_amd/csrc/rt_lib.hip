@@ -491,7 +491,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
   }
 }
 
-// parity probe: closest hit + full hit record for caller-supplied f64 rays (+ traversal counters)
+// parity probe: closest hit + full hit record for caller-supplied f64 rays (+ traversal counters).
+// TREE: which form of the acceleration structure is walked — 0 binary (64-B nodes), 1 four-wide with f32 planes,
+// 2 four-wide with binary16 planes (read from HBM: no LDS cache here) — so that every traversal the render kernels
+// use can be held against the oracle's hits ray by ray.
+template <int TREE> struct ProbeAcc;
+template <> struct ProbeAcc<0> {
+  using type = GlobalAcc;
+  static __device__ __forceinline__ type make(const Scene& sc) { return global_acc(sc); }
+};
+template <> struct ProbeAcc<1> {
+  using type = WideAcc<GlobalAcc>;
+  static __device__ __forceinline__ type make(const Scene& sc) { return type{global_acc(sc), sc.nodes4}; }
+};
+template <> struct ProbeAcc<2> {
+  using type = WideHalfAcc<GlobalAcc>;
+  static __device__ __forceinline__ type make(const Scene& sc) { return type{global_acc(sc), sc.nodes4h, nullptr, 0}; }
+};
+template <int TREE>
 __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features, const rt_ray* __restrict__ rays,
                                                     uint32_t n, rt_hit* __restrict__ out,
                                                     unsigned long long* __restrict__ trav_counters) {
@@ -501,10 +518,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
-    GlobalAcc acc = global_acc(sc);
+    const typename ProbeAcc<TREE>::type acc = ProbeAcc<TREE>::make(sc);
     PathRng rng = {i * 2654435761u + 1u, 0x9E3779B9u};  // only constant media draw (their probe hits are random)
-    HitInfo hit = traverse<GlobalAcc, uint32_t, true>(acc, sc.root, features, o, d, r.time, RT_TMIN,
-                                                      stack + threadIdx.x, RT_BLOCK, &tc, rng);
+    HitInfo hit = traverse<typename ProbeAcc<TREE>::type, uint32_t, true>(acc, acc.root(sc.root), features, o, d, r.time,
+                                                                          RT_TMIN, stack + threadIdx.x, RT_BLOCK, &tc, rng);
     rt_hit ho;
     memset(&ho, 0, sizeof(ho));
     ho.object_id = -1;
@@ -564,6 +581,7 @@ struct rt_ctx {
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
   int fused_kr = 16;
   int fused_wide = 1;  // HBM-resident fused instances walk the four-wide tree
+  int probe_tree = 0;  // rt_intersect walks: 0 the binary tree, 1 the four-wide tree (f32 planes), 2 its binary16 form
   int fused_half = 1;  // ... in its binary16 form, top levels cached in LDS, when the scene allows
   int fused_resume = 2, fused_kb = 16, fused_kn = 8;  // 0 bounce-synchronous, 1 resumable traversals, 2 by scene size  // RESUME variant of k_fused + its thresholds    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
   float* d_dbg = nullptr;
@@ -726,6 +744,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_ku = (int)value;
   } else if (k == "fused_lds") {
     ctx->fused_lds = value ? 1 : 0;
+  } else if (k == "probe_tree") {
+    if (value < 0 || value > 2) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be 0, 1 or 2");
+    ctx->probe_tree = (int)value;
   } else if (k == "fused_half") {
     ctx->fused_half = value ? 1 : 0;
   } else if (k == "fused_wide") {
@@ -1082,6 +1103,10 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
   if (n == 0) return RT_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t CH = 1u << 22;
+  if (ctx->probe_tree != 0 && scene->wide_stack + 2 > RT_STACK_DEPTH)
+    return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: the four-wide tree of this scene needs a deeper stack than the probe has");
+  if (ctx->probe_tree == 2 && !scene->half_ok)
+    return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: scene coordinates exceed the binary16 range");
   uint64_t chunk = n < CH ? n : CH;
   rt_ray* d_rays = nullptr;
   rt_hit* d_hits = nullptr;
@@ -1096,7 +1121,8 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
     uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - off);
     uint32_t blocks = std::min<uint32_t>((m + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)ctx->n_cu * 8);
     if ((e = hipMemcpyAsync(d_rays, rays + off, (size_t)m * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
-    hipLaunchKernelGGL(k_probe, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, scene->features, d_rays, m,
+    auto kern = ctx->probe_tree == 2 ? k_probe<2> : ctx->probe_tree == 1 ? k_probe<1> : k_probe<0>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, scene->features, d_rays, m,
                        d_hits, ctx->d_trav);
     ctx->probe_rays += m;
     if ((e = hipGetLastError()) != hipSuccess) { rc = RT_E_HIP; break; }
