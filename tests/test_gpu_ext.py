@@ -62,7 +62,9 @@ def test_ext_primary_hit_parity(ctx, name, width):
 
 
 @pytest.mark.parametrize("name,spp,depth", [("cornell_box", 4096, 20), ("cornell_smoke", 4096, 20),
-                                            ("final_scene_small", 2304, 20)])
+                                            ("final_scene_small", 2304, 20),
+                                            # the full scene does not fit LDS: four-wide binary16 tree, top in LDS
+                                            ("final_scene", 1024, 20)])
 @pytest.mark.parametrize("mode", [1, 0])
 def test_ext_converged_image_parity(ctx, name, spp, depth, mode):
     if mode == 0 and name != "cornell_smoke":
@@ -91,7 +93,8 @@ def test_ext_converged_image_parity(ctx, name, spp, depth, mode):
     assert rmse <= 1.5 * noise + 1e-3, (rmse, noise)
     assert (bias <= 5.0 * se + 5e-4).all(), (bias, se)
     ga, gr = np.clip(a, 0, None) ** (1 / 2.2), np.clip(ref, 0, None) ** (1 / 2.2)
-    assert psnr(np.clip(ga, 0, 1), np.clip(gr, 0, 1)) >= 28.0
+    # the full final scene at 1024 spp is noisier than the others at theirs (rmse == noise, checked above): 24 dB
+    assert psnr(np.clip(ga, 0, 1), np.clip(gr, 0, 1)) >= (24.0 if name == "final_scene" else 28.0)
 
 
 def test_background_modes(ctx):
