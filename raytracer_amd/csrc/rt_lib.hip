@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -580,6 +581,8 @@ struct rt_ctx {
   int fused_lds = 1;         // keep the scene in LDS when it fits
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
   int fused_kr = 16;
+  std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
+  std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
   int fused_wide = 1;  // HBM-resident fused instances walk the four-wide tree
   int probe_tree = 0;  // rt_intersect walks: 0 the binary tree, 1 the four-wide tree (f32 planes), 2 its binary16 form
   int fused_half = 1;  // ... in its binary16 form, top levels cached in LDS, when the scene allows
@@ -1285,10 +1288,20 @@ template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, boo
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
   auto kern = k_fused<F, KIND, BLOCK, StackT, STATS, RESUME>;
-  HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem));
-  int per_cu = 0;
-  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, smem));
+  // the LDS opt-in and the occupancy query cost tens of microseconds of host time: once per (instance, LDS size)
+  const std::pair<const void*, size_t> key(reinterpret_cast<const void*>(kern), smem);
+  auto cached = ctx->fused_occupancy.find(key);
+  if (cached == ctx->fused_occupancy.end()) {
+    size_t& opted = ctx->fused_lds_opt_in[key.first];  // the attribute is a ceiling: only ever raise it
+    if (smem > opted) {
+      HIP_TRY(ctx, hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      opted = smem;
+    }
+    int q = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, BLOCK, smem));
+    cached = ctx->fused_occupancy.emplace(key, q).first;
+  }
+  const int per_cu = cached->second;
   if (per_cu < 1) return fail(ctx, RT_E_INTERNAL, "fused kernel does not fit on a CU");
   const uint32_t waves = (uint32_t)ctx->n_cu * (uint32_t)per_cu * (BLOCK / 64);
   FusedParams fp = fp0;
