@@ -1395,7 +1395,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     const uint32_t sd = wide ? (uint32_t)scene->wide_stack + 2u : sdepth;
     fp.stack_depth = sd;
     const size_t smem = 4 * 192 * 8 + (size_t)sd * 256 * 4;
-    if (smem > 64 * 1024) return fail(ctx, RT_E_INTERNAL, "traversal stack does not fit in LDS");
+    if (smem > 160 * 1024) return fail(ctx, RT_E_INTERNAL, "traversal stack does not fit in LDS");
 #define RT_GLOBAL_DISPATCH(KS, KG)                                                                                              \
     if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KS, 256, int32_t>(ctx, scene, dc, fp, smem, st);       \
     else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KS, 256, int32_t>(ctx, scene, dc, fp, smem, st);              \
