@@ -178,9 +178,17 @@ def main():
         k_ms = sorted(kernel_ms)[len(kernel_ms) // 2]
         achieved = samples_per_rank * fps / (k_ms * 1e-3) / 1e12
         # HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE / WRITE_SIZE passes of
-        # scripts/gpu_profile.sh, summarised by scripts/summarize_profile.py); only c2 is profiled
+        # scripts/gpu_profile.sh, summarised by scripts/summarize_profile.py; c5: scripts/pmc_c5.sh)
         traffic, pmc_extra = None, None
+        traffic_src = "profiles/pmc_latest.json"
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        c5_path = os.path.join(ROOT, "profiles", "r01_c5_v9_pmc.json")
+        if args.workload == "c5" and world == 1 and os.path.exists(c5_path):
+            with open(c5_path) as f:
+                der = json.load(f).get("derived", {})
+            if "hbm_write_bytes" in der and "hbm_fetch_bytes_raw" in der:
+                traffic = 2 * der["hbm_fetch_bytes_raw"] + der["hbm_write_bytes"]  # FETCH_SIZE x2: upper bound (guide)
+                traffic_src = "profiles/r01_c5_v9_pmc.json"
         if args.workload == "c2" and world == 1 and os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 pmc = json.load(f)
@@ -203,8 +211,8 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 upper bound + WRITE_SIZE, "
-                                         "profiles/pmc_latest.json); the kernel is compute-bound, scene and path "
-                                         "state live in LDS / registers",
+                                         + traffic_src + "); the kernel is compute-bound, scene and path "
+                                         "state live in LDS / L2 / registers",
                          "kernel": "k_fused (persistent fused path-tracing kernel), per rt_render_device call",
                          "kernel_ms_per_step": k_ms, "algorithmic_flops_per_sample": fps,
                          "rays_per_sample": stats["rays"] / max(stats["paths"], 1)},
