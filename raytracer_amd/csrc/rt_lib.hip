@@ -583,6 +583,9 @@ struct rt_ctx {
   int fused_kr = 16;
   std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
   std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
+  int fused_partner = 1;  // C1/C2-class scenes: a 256-thread workgroup per CU beside the 1024-thread one (fifth wave per SIMD)
+  hipStream_t partner_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int fused_wide = 1;  // HBM-resident fused instances walk the four-wide tree
   int probe_tree = 0;  // rt_intersect walks: 0 the binary tree, 1 the four-wide tree (f32 planes), 2 its binary16 form
   int fused_half = 1;  // ... in its binary16 form, top levels cached in LDS, when the scene allows
@@ -719,6 +722,9 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->partner_stream) (void)hipStreamDestroy(ctx->partner_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return RT_OK;
@@ -750,6 +756,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "probe_tree") {
     if (value < 0 || value > 2) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be 0, 1 or 2");
     ctx->probe_tree = (int)value;
+  } else if (k == "fused_partner") {
+    ctx->fused_partner = value ? 1 : 0;
   } else if (k == "fused_half") {
     ctx->fused_half = value ? 1 : 0;
   } else if (k == "fused_wide") {
@@ -1284,6 +1292,37 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 }
 
 // ---- fused mode: one persistent kernel, no path state in HBM
+// Partner of the LDS-resident spheres instance.  That kernel is one 1024-thread workgroup per CU: four waves per SIMD
+// at 96 VGPRs, 134 KB of LDS at C2 — a fifth wave per SIMD has registers (512 - 4 x 96 = 128) but no room for a
+// second copy of the scene.  The partner is a 256-thread workgroup per CU of the instance that needs no copy: the
+// four-wide binary16 tree in whatever LDS is left (all or most of its 15 KB at C2), sphere records through L1/L2.
+// It runs on a second stream, pulls work units from the same counter and adds into the same frame accumulator.
+static bool partner_possible(const rt_ctx* ctx, const rt_scene* scene, size_t lds_main) {
+  if (!ctx->fused_partner || !scene->half_ok || scene->view.n_nodes4 >= 32768 || scene->view.n_prims >= 32768) return false;
+  const size_t fixed = 4 * 192 * 8 + (size_t)(scene->wide_stack + 2) * 256 * 2;
+  return lds_main + fixed + 16 * 64 + 1024 <= 160 * 1024;
+}
+static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams& fp_main, size_t lds_main, hipStream_t st) {
+  auto kern = k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true>;
+  FusedParams fp = fp_main;  // same work units
+  fp.stack_depth = (uint32_t)scene->wide_stack + 2u;
+  const size_t fixed = 4 * 192 * 8 + (size_t)fp.stack_depth * 256 * 2;
+  const size_t room = 160 * 1024 - lds_main - 1024;  // allocation granularity
+  fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (room - fixed) / 64);
+  const size_t smem = fixed + (size_t)fp.n_cached * 64;
+  size_t& opted = ctx->fused_lds_opt_in[reinterpret_cast<const void*>(kern)];
+  if (smem > opted) {
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    opted = smem;
+  }
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->partner_stream, ctx->ev_fork, 0));
+  hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu), dim3(256), smem, ctx->partner_stream, scene->view, ctx->d_cam, fp,
+                     ctx->d_unit_counter, ctx->d_fbacc, ctx->d_ray_total, (float*)nullptr);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->partner_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+  return RT_OK;
+}
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
@@ -1321,9 +1360,20 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
   // buffer has to outlive an asynchronous copy
   hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->d_cam);
+  constexpr bool kHasPartner = F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && RESUME && !STATS;
+  const bool partner = kHasPartner && per_cu == 1 && partner_possible(ctx, scene, smem);
+  if (partner) {
+    if (!ctx->partner_stream) {
+      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->partner_stream, hipStreamNonBlocking));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));  // frame cleared, counter reset, camera stored
+  }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->d_cam, fp, ctx->d_unit_counter, ctx->d_fbacc,
                      ctx->d_ray_total, ctx->d_dbg);
   HIP_TRY(ctx, hipGetLastError());
+  if (partner) return launch_partner(ctx, scene, fp, smem, st);
   return RT_OK;
 }
 

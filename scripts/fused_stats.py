@@ -87,3 +87,6 @@ if "--half" in sys.argv:  # HBM-resident instances: binary16 planes + LDS cache 
     for h in (1, 0, 1, 0):
         run(False, fused_half=h)
     run(True, fused_half=1)
+if "--partner" in sys.argv:  # LDS-resident spheres instance with / without its 256-thread partner workgroups
+    for v in (1, 0, 1, 0, 1, 0):
+        run(False, fused_partner=v)
