@@ -11,18 +11,20 @@ for d in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write", "pmc_l2"):
     p = os.path.join(src, d, "p_counter_collection.csv")
     if not os.path.exists(p):
         continue
-    seen = set()
+    seen = collections.defaultdict(set)  # dispatches per kernel name (a frame may launch a main and a partner instance)
     for r in csv.DictReader(open(p)):
         if "k_fused" in r["Kernel_Name"] or "k_intersect" in r["Kernel_Name"] or "k_shade" in r["Kernel_Name"]:
             out["kernel"] = out["kernel"] or r["Kernel_Name"].split("(")[0]
             out["counters"][r["Counter_Name"]] = out["counters"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-            seen.add(r["Dispatch_Id"])
-    launches[d] = len(seen)
+            seen[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    launches[d] = max((len(v) for v in seen.values()), default=0)
 # bench.py --steps 1 --warmup 0 launches the render kernel twice (timed step + the kernel-time replay): per-launch values
 n_launch = max(launches.values()) if launches else 1
 out["launches_profiled"] = n_launch
 out["counters"] = {k: v / n_launch for k, v in out["counters"].items()}
-out["note"] = "counter values are PER LAUNCH (sum over the profiled launches / launches_profiled)"
+out["note"] = ("counter values are PER FRAME (sum over the profiled kernel launches, partner instance included, / "
+               "launches_profiled); rocprofv3 serialises kernels while collecting counters, so the main instance does "
+               "the whole frame there and the partner finds the work-unit counter exhausted")
 c = out["counters"]
 der = {}
 if "SQ_INSTS_VALU" in c:
