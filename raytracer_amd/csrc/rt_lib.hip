@@ -1361,7 +1361,9 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   // buffer has to outlive an asynchronous copy
   hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->d_cam);
   constexpr bool kHasPartner = F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && RESUME && !STATS;
-  const bool partner = kHasPartner && per_cu == 1 && partner_possible(ctx, scene, smem);
+  // (a frame of under ~8 M samples is over in well under a millisecond: the second launch and its join cost more there)
+  const bool partner = kHasPartner && per_cu == 1 && (uint64_t)fp.n_tiles * 64u * fp.K >= (8ull << 20) &&
+                       partner_possible(ctx, scene, smem);
   if (partner) {
     if (!ctx->partner_stream) {
       HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->partner_stream, hipStreamNonBlocking));
