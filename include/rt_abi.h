@@ -223,6 +223,11 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value);
  * exported so tests can check it against the published Random123 known-answer vectors. */
 void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
+/* Host-side rounding used when a scene's four-wide tree is encoded with binary16 planes: the binary16 bit pattern
+ * of x rounded towards +infinity (up != 0) or -infinity.  Exported so tests can check that encoded boxes can only
+ * grow.  No reference counterpart. */
+uint32_t rt_half_round_bits(float x, int up);
+
 /* Synchronise the ctx's stream (for callers of the *_device entry points). */
 int rt_synchronize(rt_ctx* ctx);
 

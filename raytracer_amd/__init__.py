@@ -20,7 +20,7 @@ RT_E_INVALID_ARG, RT_E_HIP, RT_E_OOM, RT_E_UNSUPPORTED, RT_E_INTERNAL = -1, -2, 
 ABI_SYMBOLS = [
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free", "rt_intersect",
     "rt_render", "rt_render_device", "rt_resolve", "rt_resolve_device", "rt_get_stats", "rt_set_option",
-    "rt_philox4x32_10", "rt_synchronize",
+    "rt_philox4x32_10", "rt_half_round_bits", "rt_synchronize",
 ]
 
 
@@ -104,6 +104,8 @@ def lib():
     L.rt_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.rt_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.rt_philox4x32_10.restype = None
+    L.rt_half_round_bits.argtypes = [C.c_float, C.c_int]
+    L.rt_half_round_bits.restype = C.c_uint32
     L.rt_synchronize.argtypes = [vp]
     _gpu = L
     return L

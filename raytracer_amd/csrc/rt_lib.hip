@@ -641,11 +641,29 @@ static void xoro_short_jump(uint64_t s[2]) {
   s[1] = s1;
 }
 
+// binary16 bits of x rounded towards +inf (up) or -inf: the nearest value, stepped once if it lies on the wrong side
+static uint16_t half_round(float x, bool up) {
+  _Float16 h = (_Float16)x;
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  const float back = (float)h;
+  if (std::isnan(x)) return b;
+  if (up ? back < x : back > x) {
+    const bool neg = b & 0x8000u;
+    if ((b & 0x7FFFu) == 0) b = up ? 0x0001u : 0x8001u;  // from +-0 to the smallest denormal of the wanted sign
+    else if (up != neg) b++;                            // away from zero
+    else b--;                                          // towards zero
+  }
+  return b;
+}
+
 extern "C" {
 
 int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_init_err.c_str(); }
+
+uint32_t rt_half_round_bits(float x, int up) { return half_round(x, up != 0); }
 
 void rt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -777,21 +795,6 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
 }
 
 // ------------------------------------------------------------------------------------------------ scene upload
-// binary16 bits of x rounded towards +inf (up) or -inf: the nearest value, stepped once if it lies on the wrong side
-static uint16_t half_round(float x, bool up) {
-  _Float16 h = (_Float16)x;
-  uint16_t b;
-  memcpy(&b, &h, 2);
-  const float back = (float)h;
-  if (std::isnan(x)) return b;
-  if (up ? back < x : back > x) {
-    const bool neg = b & 0x8000u;
-    if ((b & 0x7FFFu) == 0) b = up ? 0x0001u : 0x8001u;  // from +-0 to the smallest denormal of the wanted sign
-    else if (up != neg) b++;                            // away from zero
-    else b--;                                          // towards zero
-  }
-  return b;
-}
 static bool finite3(const double* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
 
 static int validate_texture_graph(rt_ctx* ctx, const rt_scene_desc* d) {

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_abi_header_symbols_all_exported():
     hdr = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|void|uint32_t|const char\*)\s+(rt_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(ra.ABI_SYMBOLS), declared ^ set(ra.ABI_SYMBOLS)
     lib = ra.lib()
     for name in declared:
@@ -229,3 +229,26 @@ def test_image_writers_ppm_and_png(tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / "a.png").convert("RGB")), want)
     with pytest.raises(RuntimeError):
         ra.write_image(tmp_path / "no_such_dir" / "a.png", img)
+
+
+def test_binary16_plane_rounding_is_outward_and_tight():
+    """The four-wide tree's 64-B nodes keep their planes in binary16 (rt_lib.hip half_round): lower planes round
+    towards -inf, upper planes towards +inf, by at most one binary16 step, so an encoded box can only grow."""
+    L = ra.lib()
+    rng = np.random.default_rng(9)
+    xs = np.concatenate([rng.normal(0, 1, 4000) * 10.0 ** rng.uniform(-9, 5.2, 4000), [0.0, -0.0, 1.0, -1.0, 65504.0,
+                         -65504.0, 65505.0, 70000.0, -1e30, 1e30, 5.96e-8, -5.96e-8, 1e-12, -1e-12, 6.1e-5, 0.1, -0.1,
+                         2049.0, -2049.0, np.inf, -np.inf]]).astype(np.float32)
+    for up in (0, 1):
+        bits = np.array([L.rt_half_round_bits(float(x), up) for x in xs], dtype=np.uint16)
+        h = bits.view(np.float16).astype(np.float64)
+        x64 = xs.astype(np.float64)
+        assert (h >= x64).all() if up else (h <= x64).all()
+        # tight: the neighbouring binary16 value on the other side is already past x
+        with np.errstate(over="ignore"):  # stepping from 65504 towards +inf overflows to inf, as intended
+            nb = np.nextafter(bits.view(np.float16), np.float16(-np.inf if up else np.inf)).astype(np.float64)
+        exact = h == x64
+        assert (exact | ((nb < x64) if up else (nb > x64))).all()
+    assert L.rt_half_round_bits(1.0, 0) == 0x3C00 and L.rt_half_round_bits(1.0, 1) == 0x3C00
+    assert L.rt_half_round_bits(70000.0, 0) == 0x7BFF and L.rt_half_round_bits(70000.0, 1) == 0x7C00  # 65504 / +inf
+    assert L.rt_half_round_bits(-70000.0, 1) == 0xFBFF and L.rt_half_round_bits(-70000.0, 0) == 0xFC00
