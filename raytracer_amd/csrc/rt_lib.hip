@@ -386,7 +386,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
         have_unit = false;
         total = 0; next = 0;
       } else {
-        const uint32_t tile = u % fp.n_tiles, chunk = u / fp.n_tiles;
+        // chunk-major, tiles from the bottom row up: the units that start last are then the top rows, which in the
+        // reference's scenes look at the sky (cheap paths make a short tail)
+        const uint32_t tile = fp.n_tiles - 1u - u % fp.n_tiles, chunk = u / fp.n_tiles;
         x0 = (tile % fp.tiles_x) * 8; y0 = (tile / fp.tiles_x) * 8;
         k_lo = chunk * fp.Ku;
         total = 64u * min(fp.Ku, fp.K - k_lo);
@@ -466,6 +468,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
       for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
       if (lane == 0) atomicAdd(&dbg[k], x);
     }
+    // longest wave lifetime (positive floats order like their bit patterns): against the mean, the frame's tail
+    if (lane == 0) atomicMax(reinterpret_cast<int*>(&dbg[13]), __float_as_int(st_ttotal * 64.0f));
   }
 }
 
