@@ -212,7 +212,8 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * schedule: 0 bounce-synchronous, 1 resumable, 2 = by scene size, default) with "fused_kb" / "fused_kn" /
  * "fused_kr" (hand-back, node-loop exit and regeneration thresholds, 1..64), "fused_wide" / "fused_half" (scenes
  * that do not fit LDS: 1 = four-wide tree / its binary16 form with the top levels cached in LDS, defaults; 0 = the
- * binary tree / f32 planes, kept as cross-checks), "fused_partner" (1 = default: sphere scenes resident in LDS get a second, 256-thread
+ * binary tree / f32 planes, kept as cross-checks), "fused_tail" / "fused_tail_ku" (how many of the last passes over the tiles are handed out in shorter work
+ * units, and of how many samples; 4 / 0 = half, defaults; never changes the frame), "fused_partner" (1 = default: sphere scenes resident in LDS get a second, 256-thread
  * workgroup per CU of the HBM-resident instance; the frame is unchanged), "probe_tree" (which tree rt_intersect walks: 0 binary, default; 1 four-wide f32; 2 four-wide
  * binary16), "fused_stats" (1 = instrumented kernel, fills rt_stats.dbg).  Thresholds and unit size never change the frame; the kernel variants agree up to
  * the f32 rounding of separately compiled shading code.  Unknown keys and out-of-range values

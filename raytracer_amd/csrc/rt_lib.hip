@@ -188,9 +188,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float* __restrict
 // regardless of path length.  Radiance is summed in per-wave LDS accumulators as 2^-40 fixed point (integer
 // adds are order-independent => bit-reproducible frames) and flushed to a u64 frame with global atomics.
 // No path state ever touches HBM.
+#define RT_UNIT_LEVELS 2
 struct FusedParams {
   uint32_t K, s_begin, s_stride, Ku;
   uint32_t tiles_x, n_tiles, n_units;
+  // unit schedule: level i covers units [level_unit0[i], level_unit0[i+1]) = passes over all tiles with level_ku[i]
+  // sample indices per unit, starting at sample index level_k0[i]; unused levels start at n_units
+  uint32_t level_unit0[RT_UNIT_LEVELS], level_k0[RT_UNIT_LEVELS], level_ku[RT_UNIT_LEVELS];
   uint32_t k0, k1;
   uint32_t stack_depth;
   uint32_t kb, kn;  // RESUME variant: hand-back / node-loop exit thresholds (traverse_resume)
@@ -388,10 +392,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
       } else {
         // chunk-major, tiles from the bottom row up: the units that start last are then the top rows, which in the
         // reference's scenes look at the sky (cheap paths make a short tail)
-        const uint32_t tile = fp.n_tiles - 1u - u % fp.n_tiles, chunk = u / fp.n_tiles;
+        // passes over the tiles, level by level: units get shorter towards the end of the frame (see launch_fused)
+        uint32_t lv = 0;
+#pragma unroll
+        for (uint32_t i = 1; i < RT_UNIT_LEVELS; i++) lv = u >= fp.level_unit0[i] ? i : lv;
+        const uint32_t v = u - fp.level_unit0[lv];
+        const uint32_t tile = v % fp.n_tiles, pass = v / fp.n_tiles;
         x0 = (tile % fp.tiles_x) * 8; y0 = (tile / fp.tiles_x) * 8;
-        k_lo = chunk * fp.Ku;
-        total = 64u * min(fp.Ku, fp.K - k_lo);
+        k_lo = fp.level_k0[lv] + pass * fp.level_ku[lv];
+        total = 64u * min(fp.level_ku[lv], fp.K - k_lo);
         next = 0;
         have_unit = true;
       }
@@ -587,6 +596,7 @@ struct rt_ctx {
   int fused_kr = 16;
   std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
   std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
+  int fused_tail = 4, fused_tail_ku = 0;  // the last passes' worth of samples goes out in shorter units (launch_fused)
   int fused_partner = 1;  // C1/C2-class scenes: a 256-thread workgroup per CU beside the 1024-thread one (fifth wave per SIMD)
   hipStream_t partner_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -778,6 +788,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "probe_tree") {
     if (value < 0 || value > 2) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be 0, 1 or 2");
     ctx->probe_tree = (int)value;
+  } else if (k == "fused_tail" || k == "fused_tail_ku") {
+    if (value < 0 || value > 64) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 0..64");
+    (k == "fused_tail" ? ctx->fused_tail : ctx->fused_tail_ku) = (int)value;
   } else if (k == "fused_partner") {
     ctx->fused_partner = value ? 1 : 0;
   } else if (k == "fused_half") {
@@ -1362,7 +1375,34 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   }
   fp.Ku = (fp.K + chunks - 1) / chunks;
   chunks = (fp.K + fp.Ku - 1) / fp.Ku;
-  fp.n_units = fp.n_tiles * chunks;
+  // The frame ends when the last wave ends.  Unit costs spread widely (a tile of glass spheres takes 5-7 times the
+  // average), and a costly unit that starts in the last pass over the tiles overruns all the others by most of its
+  // length.  So units get shorter towards the end of the frame: with many passes over the tiles (C2: 15 of 7
+  // samples) all but the last `fused_tail` (4) go out at full size and the rest in units of `fused_tail_ku` samples
+  // (0 = half): -2.5 % on C2; single-sample units cost more than they save (+1 %).  With a single pass (C5 at 4K:
+  // the tiles alone are units enough) halving sizes K/2, K/4, ... bought nothing (54.3 vs 53.9 ms) and are not used.
+  // The schedule never changes the frame (a sample's key is its index, sums are integers).
+  struct Level { uint32_t k0, ku, passes; } lv[RT_UNIT_LEVELS];
+  int n_lv = 0;
+  const uint32_t kt = ctx->fused_tail_ku > 0 ? (uint32_t)ctx->fused_tail_ku : (fp.Ku + 1) / 2;
+  if (ctx->fused_tail > 0 && chunks >= 4 && kt < fp.Ku) {
+    const uint32_t main_chunks = chunks - std::min<uint32_t>((uint32_t)ctx->fused_tail, chunks - 1);
+    const uint32_t k_tail = main_chunks * fp.Ku;
+    lv[n_lv++] = {0u, fp.Ku, main_chunks};
+    lv[n_lv++] = {k_tail, kt, (fp.K - k_tail + kt - 1) / kt};
+  } else {
+    lv[n_lv++] = {0u, fp.Ku, chunks};
+  }
+  uint32_t unit0 = 0;
+  for (int i = 0; i < RT_UNIT_LEVELS; i++) {
+    if (i < n_lv) {
+      fp.level_unit0[i] = unit0; fp.level_k0[i] = lv[i].k0; fp.level_ku[i] = lv[i].ku;
+      unit0 += fp.n_tiles * lv[i].passes;
+    } else {
+      fp.level_unit0[i] = 0xFFFFFFFFu; fp.level_k0[i] = fp.K; fp.level_ku[i] = 1;
+    }
+  }
+  fp.n_units = unit0;
   const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
   // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
   // buffer has to outlive an asynchronous copy

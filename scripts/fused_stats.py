@@ -90,3 +90,9 @@ if "--half" in sys.argv:  # HBM-resident instances: binary16 planes + LDS cache 
 if "--partner" in sys.argv:  # LDS-resident spheres instance with / without its 256-thread partner workgroups
     for v in (1, 0, 1, 0, 1, 0):
         run(False, fused_partner=v)
+if "--tail" in sys.argv:  # the last `fused_tail` passes' worth of samples in units of `fused_tail_ku` sample indices
+    for t, k in ((0, 0), (4, 0), (4, 4), (2, 3), (6, 4), (4, 5), (4, 1), (0, 0), (4, 0)):
+        run(False, fused_tail=t, fused_tail_ku=k)
+if "--tail0" in sys.argv:
+    for t in (4, 0, 4, 0):
+        run(False, fused_tail=t)
