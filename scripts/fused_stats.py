@@ -96,3 +96,6 @@ if "--tail" in sys.argv:  # the last `fused_tail` passes' worth of samples in un
 if "--tail0" in sys.argv:
     for t in (4, 0, 4, 0):
         run(False, fused_tail=t)
+if "--ku5" in sys.argv:
+    for ku in (0, 8, 4, 2, 0, 8, 4):
+        run(False, fused_ku=ku)
