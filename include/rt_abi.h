@@ -180,9 +180,11 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
 
 /* Render samples {s = sample_begin + k*sample_stride < sample_end} of every pixel and write the
  * UN-NORMALISED linear RGB sums (row-major, W*H*3 f32) to `out_sum`.  For the UNIFORM sampler s enumerates the
- * grid cells (yi, xi) = (s / n, s % n); for RANDOM s = 0..n-1.  `seed` keys the counter-based RNG
- * (Philox4x32-10, counter = pixel, sample, bounce, purpose), so the sum over any partition of the sample
- * indices equals the single-call result up to f32 summation order.
+ * grid cells (yi, xi) = (s / n, s % n); for RANDOM s = 0..n-1.  `seed` keys the counter-based RNG: Philox4x32-10 is
+ * evaluated once per path with counter = (pixel, sample index, 0, 0) and key = seed; two of its words feed the lens
+ * sample and two seed the path's own xoroshiro64** stream for all later draws.  A path therefore depends only on
+ * (seed, pixel, sample index), so the sum over any partition of the sample indices equals the single-call result up
+ * to f32 summation order.
  * Replaces: the body of Camera::render / render_rect / sample_pixel / sample_point / ray_color
  * (src/camera/mod.rs:54-214).  rt_render takes a HOST output pointer (blocking; includes the D2H copy);
  * rt_render_device takes a DEVICE pointer and a hipStream_t (NULL = the ctx's stream) and is asynchronous

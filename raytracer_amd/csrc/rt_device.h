@@ -103,7 +103,7 @@ struct Hits {
 #define RT_F_TEX_ANY 7u
 
 // ----------------------------------------------------------------------------------------------- RNG
-// Philox4x32-10 (Salmon et al., SC'11).  Counter = (pixel, sample, bounce, purpose), key = seed.
+// Philox4x32-10 (Salmon et al., SC'11).  generate_ray evaluates it once per path: counter = (pixel, sample, 0, 0), key = seed.
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1, uint32_t out[4]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;

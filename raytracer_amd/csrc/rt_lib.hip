@@ -826,8 +826,11 @@ static int validate_texture_graph(rt_ctx* ctx, const rt_scene_desc* d) {
         return fail(ctx, RT_E_INVALID_ARG, "texture " + std::to_string(i) + ": checker children must precede it");
     }
     if (t.kind == RT_TEX_IMAGE) {
-      uint64_t bytes = (uint64_t)t.width * t.height * 4;
-      if ((t.texel_offset & 3) || t.texel_offset + bytes > d->n_texel_bytes || (bytes && !d->texels))
+      // checked arithmetic: width * height * 4 and offset + bytes must not wrap, and the device indexes texels with 32 bits
+      const uint64_t texels = (uint64_t)t.width * t.height;  // < 2^64: both factors are 32-bit
+      const uint64_t avail = d->n_texel_bytes / 4;
+      if ((t.texel_offset & 3) || texels > avail || t.texel_offset / 4 > avail - texels || (texels && !d->texels) ||
+          t.texel_offset / 4 + texels > 0xFFFFFFFFull)
         return fail(ctx, RT_E_INVALID_ARG, "texture " + std::to_string(i) + ": texel range outside the blob");
     }
   }
@@ -972,12 +975,14 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     Material& o = mats[i];
     memset(&o, 0, sizeof(o));
     o.kind = m.kind;
-    o.tex = m.tex;
+    // METAL and DIELECTRIC take no texture: whatever the caller left in `tex` (a zero-initialised struct says 0) is ignored
+    const bool takes_tex = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT || m.kind == RT_MAT_ISOTROPIC;
+    o.tex = takes_tex ? m.tex : -1;
     for (int a = 0; a < 3; a++) o.albedo[a] = (float)m.albedo[a];
     o.fuzz = (float)m.fuzz;
     o.ior = (float)m.ior;
     // inline solid-colour textures so the common case needs no texture fetch
-    if (m.tex >= 0 && d->textures[(size_t)m.tex].kind == RT_TEX_SOLID) {
+    if (o.tex >= 0 && d->textures[(size_t)m.tex].kind == RT_TEX_SOLID) {
       for (int a = 0; a < 3; a++) o.albedo[a] = (float)d->textures[(size_t)m.tex].rgb[a];
       o.tex = -1;
     }
@@ -1393,20 +1398,21 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   } else {
     lv[n_lv++] = {0u, fp.Ku, chunks};
   }
-  uint32_t unit0 = 0;
+  uint64_t unit0 = 0;
   for (int i = 0; i < RT_UNIT_LEVELS; i++) {
     if (i < n_lv) {
-      fp.level_unit0[i] = unit0; fp.level_k0[i] = lv[i].k0; fp.level_ku[i] = lv[i].ku;
-      unit0 += fp.n_tiles * lv[i].passes;
+      fp.level_unit0[i] = (uint32_t)unit0; fp.level_k0[i] = lv[i].k0; fp.level_ku[i] = lv[i].ku;
+      unit0 += (uint64_t)fp.n_tiles * lv[i].passes;
+      if (unit0 >= 0xFFFFFFFFull) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: more work units than the 32-bit unit counter holds (raise fused_ku)");
     } else {
       fp.level_unit0[i] = 0xFFFFFFFFu; fp.level_k0[i] = fp.K; fp.level_ku[i] = 1;
     }
   }
-  fp.n_units = unit0;
+  fp.n_units = (uint32_t)unit0;
   const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
   // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
   // buffer has to outlive an asynchronous copy
-  hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->d_cam);
+  hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->fs->cam);
   constexpr bool kHasPartner = F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && RESUME && !STATS;
   // (a frame of under ~8 M samples is over in well under a millisecond: the second launch and its join cost more there)
   const bool partner = kHasPartner && per_cu == 1 && (uint64_t)fp.n_tiles * 64u * fp.K >= (8ull << 20) &&
