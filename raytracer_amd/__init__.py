@@ -15,12 +15,13 @@ LIB_HOST_PATH = os.path.join(HERE, "libraytracer_host.so")
 
 RT_OK = 0
 RT_E_INVALID_ARG, RT_E_HIP, RT_E_OOM, RT_E_UNSUPPORTED, RT_E_INTERNAL = -1, -2, -3, -4, -5
+RT_NOALLOC_MAX_PIXELS = 1 << 20  # include/rt_abi.h
 
 # every symbol include/rt_abi.h declares
 ABI_SYMBOLS = [
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free", "rt_intersect",
     "rt_render", "rt_render_device", "rt_resolve", "rt_resolve_device", "rt_get_stats", "rt_set_option",
-    "rt_philox4x32_10", "rt_half_round_bits", "rt_synchronize",
+    "rt_philox4x32_10", "rt_half_round_bits", "rt_synchronize", "rt_render_device_noalloc",
 ]
 
 
@@ -98,6 +99,7 @@ def lib():
     L.rt_intersect.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.rt_render_device_noalloc.argtypes = L.rt_render_device.argtypes
     L.rt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp]
     L.rt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
@@ -234,11 +236,14 @@ class DeviceScene:
                                             sample_stride, out.ctypes.data))
         return out
 
-    def render_device(self, cam, d_out_ptr, seed=0, sample_begin=0, sample_end=None, sample_stride=1, stream=None):
+    def render_device(self, cam, d_out_ptr, seed=0, sample_begin=0, sample_end=None, sample_stride=1, stream=None,
+                      no_alloc=False):
+        """rt_render_device, or rt_render_device_noalloc (scratch in the library's fixed device array)."""
         if sample_end is None:
             sample_end = cam.sampler_n * cam.sampler_n if cam.sampler_kind == 0 else cam.sampler_n
-        self.ctx.check(self.ctx.L.rt_render_device(self.ctx.h, self.h, C.byref(cam), seed, sample_begin, sample_end,
-                                                   sample_stride, d_out_ptr, stream))
+        fn = self.ctx.L.rt_render_device_noalloc if no_alloc else self.ctx.L.rt_render_device
+        self.ctx.check(fn(self.ctx.h, self.h, C.byref(cam), seed, sample_begin, sample_end, sample_stride, d_out_ptr,
+                          stream))
 
 
 def resolve(ctx, sums, spp, gamma=2.2, want_u8=False):

@@ -558,6 +558,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
 
 // ================================================================================================ host side
 
+// ---- fixed scratch of rt_render_device_noalloc (callers that cannot allocate: HIP graph capture, serving loops).
+// One copy per GPU, held until the process ends: W*H*3 u64 frame accumulators for frames of up to RT_NOALLOC_MAX_PIXELS
+// pixels (24 MiB) + 1 KiB of control words (camera block, ray counter, unit counter).  Host code never passes the
+// array's name to a kernel: rt_init asks for its address on the ctx's device (hipGetSymbolAddress) and keeps it.
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_PIXELS * 3 * 8 + 1024)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+static_assert(sizeof(Camera) <= 512, "camera block must fit the scratch's control area");
+
 struct rt_scene {
   BvhNode* d_nodes = nullptr;
   float4* d_nodes4 = nullptr;  // four-wide form of the tree (HBM-resident fused instances)
@@ -583,6 +591,14 @@ struct WorkBuffers {
   float *Lr = nullptr, *Lg = nullptr, *Lb = nullptr;
 };
 
+// Device memory a fused render needs beyond its inputs and outputs.
+struct FrameScratch {
+  unsigned long long* fbacc = nullptr;      // W*H*3 fixed-point frame accumulators
+  uint32_t* unit_counter = nullptr;         // work-unit counter of the persistent kernel
+  Camera* cam = nullptr;                    // camera block of the render in flight (read with scalar loads)
+  unsigned long long* ray_total = nullptr;  // rays traced (stats)
+};
+
 struct rt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -606,15 +622,16 @@ struct rt_ctx {
   int fused_resume = 2, fused_kb = 16, fused_kn = 8;  // 0 bounce-synchronous, 1 resumable traversals, 2 by scene size  // RESUME variant of k_fused + its thresholds    // diagnostic: workgroup size of the LDS-resident variant (1024 / 512 / 256)
   float* d_dbg = nullptr;
   WorkBuffers wb;
-  uint32_t* d_unit_counter = nullptr;
-  Camera* d_cam = nullptr;  // camera block of the render in flight (fused mode reads it with scalar loads)
-  unsigned long long* d_fbacc = nullptr;
+  // per-render device scratch: `own` is allocated by the library (rt_render_device grows it on demand), `fixed` lives in
+  // the file-scope __device__ array `scratch` (rt_render_device_noalloc); `fs` is the set of the render being issued
+  FrameScratch own, fixed;
+  const FrameScratch* fs = &own;
+  const unsigned long long* last_ray_total = nullptr;  // ray counter of the last render (rt_get_stats)
   size_t fbacc_cap = 0;
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
   unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
   size_t counts_cap = 0;
-  unsigned long long* d_ray_total = nullptr;
   uint4* d_noise_table = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_a = nullptr, ev_b = nullptr;
   bool timing_pending = false;
@@ -708,9 +725,27 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&ctx->d_ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_unit_counter, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->own.ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->own.unit_counter, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->own.cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(ctx->own.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  ctx->last_ray_total = ctx->own.ray_total;
+  {
+    // rt_render_device_noalloc: this device's copy of the file-scope array `scratch`.  The array's name is only a
+    // host-side handle; the address the kernels get is the one hipGetSymbolAddress returns with the device current.
+    void* base = nullptr;
+    if ((e = hipGetSymbolAddress(&base, HIP_SYMBOL(scratch))) != hipSuccess || !base) return bail("hipGetSymbolAddress(scratch)", e);
+    unsigned char* b = static_cast<unsigned char*>(base);
+    ctx->fixed.fbacc = reinterpret_cast<unsigned long long*>(b);
+    unsigned char* ctl = b + (size_t)RT_NOALLOC_MAX_PIXELS * 3 * 8;
+    ctx->fixed.cam = reinterpret_cast<Camera*>(ctl);
+    ctx->fixed.ray_total = reinterpret_cast<unsigned long long*>(ctl + 512);
+    ctx->fixed.unit_counter = reinterpret_cast<uint32_t*>(ctl + 768);
+  }
+  // the partner workgroups' stream and fork / join events (launch_partner): created here so that no render call has to
+  if ((e = hipStreamCreateWithFlags(&ctx->partner_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->d_dbg, 0, 16 * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
@@ -743,10 +778,10 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_work(ctx);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-  if (ctx->d_ray_total) (void)hipFree(ctx->d_ray_total);
-  if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
-  if (ctx->d_cam) (void)hipFree(ctx->d_cam);
-  if (ctx->d_fbacc) (void)hipFree(ctx->d_fbacc);
+  if (ctx->own.ray_total) (void)hipFree(ctx->own.ray_total);
+  if (ctx->own.unit_counter) (void)hipFree(ctx->own.unit_counter);
+  if (ctx->own.cam) (void)hipFree(ctx->own.cam);
+  if (ctx->own.fbacc) (void)hipFree(ctx->own.fbacc);
   if (ctx->d_trav) (void)hipFree(ctx->d_trav);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
   if (ctx->d_noise_table) (void)hipFree(ctx->d_noise_table);
@@ -1307,7 +1342,7 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
       tm.begin();
       const uint32_t ablocks = std::min<uint32_t>((npp + 3) / 4, max_blocks);
       hipLaunchKernelGGL(k_accumulate, dim3(ablocks), dim3(RT_BLOCK), 0, st, ctx->wb.Lr, ctx->wb.Lg, ctx->wb.Lb,
-                         d_out_sum, pp, npp, ctx->d_counts, depth, ctx->d_ray_total);
+                         d_out_sum, pp, npp, ctx->d_counts, depth, ctx->fs->ray_total);
       tm.end(ctx->stats.ms_accumulate);
       ctx->stats.passes++;
     }
@@ -1341,8 +1376,8 @@ static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams&
     opted = smem;
   }
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->partner_stream, ctx->ev_fork, 0));
-  hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu), dim3(256), smem, ctx->partner_stream, scene->view, ctx->d_cam, fp,
-                     ctx->d_unit_counter, ctx->d_fbacc, ctx->d_ray_total, (float*)nullptr);
+  hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu), dim3(256), smem, ctx->partner_stream, scene->view, ctx->fs->cam, fp,
+                     ctx->fs->unit_counter, ctx->fs->fbacc, ctx->fs->ray_total, (float*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->partner_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -1418,15 +1453,10 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   const bool partner = kHasPartner && per_cu == 1 && (uint64_t)fp.n_tiles * 64u * fp.K >= (8ull << 20) &&
                        partner_possible(ctx, scene, smem);
   if (partner) {
-    if (!ctx->partner_stream) {
-      HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->partner_stream, hipStreamNonBlocking));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));  // frame cleared, counter reset, camera stored
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->d_cam, fp, ctx->d_unit_counter, ctx->d_fbacc,
-                     ctx->d_ray_total, ctx->d_dbg);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->fs->cam, fp, ctx->fs->unit_counter, ctx->fs->fbacc,
+                     ctx->fs->ray_total, ctx->d_dbg);
   HIP_TRY(ctx, hipGetLastError());
   if (partner) return launch_partner(ctx, scene, fp, smem, st);
   return RT_OK;
@@ -1449,16 +1479,16 @@ static int launch_variant(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, 
 static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const Camera& dc, uint64_t seed,
                         uint32_t sample_begin, uint32_t sample_stride, uint32_t K, float* d_out_sum, hipStream_t st) {
   const size_t n_val = (size_t)cam->width * cam->height * 3;
-  if (ctx->fbacc_cap < n_val) {
+  if (ctx->fs == &ctx->own && ctx->fbacc_cap < n_val) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_fbacc) (void)hipFree(ctx->d_fbacc);
-    ctx->d_fbacc = nullptr;
+    if (ctx->own.fbacc) (void)hipFree(ctx->own.fbacc);
+    ctx->own.fbacc = nullptr;
     ctx->fbacc_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_fbacc, n_val * 8));
+    HIP_TRY(ctx, hipMalloc(&ctx->own.fbacc, n_val * 8));
     ctx->fbacc_cap = n_val;
   }
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_fbacc, 0, n_val * 8, st));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->fbacc, 0, n_val * 8, st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->unit_counter, 0, sizeof(uint32_t), st));
   FusedParams fp;
   memset(&fp, 0, sizeof(fp));
   fp.K = K; fp.s_begin = sample_begin; fp.s_stride = sample_stride;
@@ -1532,7 +1562,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   if (rc) return rc;
   tm.end(ctx->stats.ms_intersect);
   const uint32_t blocks = std::min<uint32_t>((uint32_t)((n_val + RT_BLOCK - 1) / RT_BLOCK), (uint32_t)ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_fix_to_float, dim3(blocks), dim3(RT_BLOCK), 0, st, ctx->d_fbacc, d_out_sum, (uint32_t)n_val);
+  hipLaunchKernelGGL(k_fix_to_float, dim3(blocks), dim3(RT_BLOCK), 0, st, ctx->fs->fbacc, d_out_sum, (uint32_t)n_val);
   HIP_TRY(ctx, hipGetLastError());
   ctx->stats.passes = 1;
   return RT_OK;
@@ -1540,8 +1570,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
 
 extern "C" {
 
-int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
-                     uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
+static int render_device_impl(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+                              uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream, bool no_alloc) {
   if (!ctx) return RT_E_INVALID_ARG;
   if (!scene || !cam || !d_out_sum) return fail(ctx, RT_E_INVALID_ARG, "rt_render: NULL argument");
   if (sample_stride == 0) return fail(ctx, RT_E_INVALID_ARG, "rt_render: sample_stride must be >= 1");
@@ -1550,14 +1580,25 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
   if (rc) return rc;
   const uint64_t spp_total = cam->sampler_kind == RT_SAMPLER_UNIFORM ? (uint64_t)cam->sampler_n * cam->sampler_n : cam->sampler_n;
   if (sample_end > spp_total) return fail(ctx, RT_E_INVALID_ARG, "rt_render: sample_end exceeds the sampler's sample count");
+  const uint32_t n_pix = cam->width * cam->height;
+  if (no_alloc) {
+    if (ctx->mode != 1)
+      return fail(ctx, RT_E_UNSUPPORTED, "rt_render_device_noalloc: only the fused mode (option mode = 1) runs without allocating");
+    if (n_pix > RT_NOALLOC_MAX_PIXELS)
+      return fail(ctx, RT_E_UNSUPPORTED, "rt_render_device_noalloc: frame of " + std::to_string(n_pix) + " pixels exceeds the fixed scratch (" +
+                                             std::to_string(RT_NOALLOC_MAX_PIXELS) + " pixels); use rt_render_device");
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-  const uint32_t n_pix = cam->width * cam->height;
-  const uint32_t K = sample_begin < sample_end ? (sample_end - sample_begin + sample_stride - 1) / sample_stride : 0;
-  if (K > 65535u * 64u) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: too many samples per pixel in one call");
+  // (64-bit: a stride close to 2^32 must not wrap the rounding-up)
+  const uint64_t K64 = sample_begin < sample_end ? ((uint64_t)(sample_end - sample_begin) + sample_stride - 1) / sample_stride : 0;
+  if (K64 > 65535ull * 64ull) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: too many samples per pixel in one call");
+  const uint32_t K = (uint32_t)K64;
+  ctx->fs = no_alloc ? &ctx->fixed : &ctx->own;
   ctx->stats = rt_stats();
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ray_total, 0, sizeof(unsigned long long), st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->ray_total, 0, sizeof(unsigned long long), st));
+  ctx->last_ray_total = ctx->fs->ray_total;
   if (K > 0 && cam->max_depth > 0) {
     ctx->stats.paths = (uint64_t)n_pix * K;
     if (ctx->mode == 0) {
@@ -1573,6 +1614,18 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
   HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
   ctx->timing_pending = true;
   return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+                     uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
+  return render_device_impl(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out_sum, hip_stream, false);
+}
+
+// Same render with every scratch buffer (frame accumulators, unit counter, camera block, ray counter) in the
+// file-scope device array `scratch`: no hipMalloc / hipFree / stream or event creation on this path.
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
+                             uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
+  return render_device_impl(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out_sum, hip_stream, true);
 }
 
 int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
@@ -1603,7 +1656,7 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->stats.ms_total = ms;
     unsigned long long rays = 0;
-    HIP_TRY(ctx, hipMemcpy(&rays, ctx->d_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(&rays, ctx->last_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
     ctx->stats.rays = rays;
     HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
     unsigned long long trav[2] = {0, 0};
