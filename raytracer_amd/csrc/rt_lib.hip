@@ -182,19 +182,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------ fused mode
-// One persistent kernel: every wave pulls work units (an 8x8-pixel tile x Ku sample indices) from a global
-// counter and runs generate -> (intersect -> shade)* for them with per-lane path regeneration: a lane whose path
-// ended takes the next sample of the unit's pool (wave64 ballot + prefix, no atomics), so lanes stay busy
-// regardless of path length.  Radiance is summed in per-wave LDS accumulators as 2^-40 fixed point (integer
-// adds are order-independent => bit-reproducible frames) and flushed to a u64 frame with global atomics.
-// No path state ever touches HBM.
-#define RT_UNIT_LEVELS 2
+// One persistent kernel.  A WORKGROUP owns whole 8x8-pixel tiles: it claims a tile from a global counter, renders ALL of
+// the tile's sample indices itself and writes the tile's 64 x 3 sums to the frame exactly once, with plain stores — no
+// frame-wide accumulator, no global atomics, nothing to clear or convert afterwards.  Inside the workgroup the tile's
+// samples are handed out to the waves in chunks (64 pixels x Ku sample indices) from a cursor in LDS, radiance is summed
+// in the tile's LDS slot as 2^-40 fixed point (integer adds are order independent => bit-reproducible frames, whatever
+// wave traces a sample), and the lane that finishes the tile's last path has its wave write the slot out.  A workgroup
+// keeps up to RT_MAX_SLOTS tiles in flight (one being handed out, the others waiting for their longest paths), so
+// no lane ever idles through a tile's drain.  Per lane: path regeneration from the wave's current chunk (wave64 ballot
+// + prefix).  No path state ever touches HBM.
+#define RT_MAX_SLOTS 16
+#define RT_TILE_LEVELS 3
 struct FusedParams {
   uint32_t K, s_begin, s_stride, Ku;
-  uint32_t tiles_x, n_tiles, n_units;
-  // unit schedule: level i covers units [level_unit0[i], level_unit0[i+1]) = passes over all tiles with level_ku[i]
-  // sample indices per unit, starting at sample index level_k0[i]; unused levels start at n_units
-  uint32_t level_unit0[RT_UNIT_LEVELS], level_k0[RT_UNIT_LEVELS], level_ku[RT_UNIT_LEVELS];
+  // Tile list.  The frame is cut into horizontal bands, each tiled with squares of its own side (8, 4 or 2 pixels):
+  // band i holds tiles [lvl_begin[i], lvl_begin[i + 1]) of the list, starts at image row lvl_y0[i] and has lvl_tiles_x[i]
+  // tiles of side 1 << lvl_shift[i] per row.  Large tiles come first; the small ones at the end of the list keep the
+  // frame's tail short (a workgroup's last tile is then a few hundred paths, not thousands).  The main kernel takes
+  // tiles from the front of the list, the partner workgroups (from_back) from its end: one 64-bit counter, low word =
+  // tiles taken at the front, high word = tiles taken at the back, a claim is valid while front + back < n_tiles.
+  uint32_t n_tiles, from_back;
+  uint32_t lvl_begin[RT_TILE_LEVELS + 1], lvl_y0[RT_TILE_LEVELS], lvl_tiles_x[RT_TILE_LEVELS], lvl_shift[RT_TILE_LEVELS];
   uint32_t k0, k1;
   uint32_t stack_depth;
   uint32_t kb, kn;  // RESUME variant: hand-back / node-loop exit thresholds (traverse_resume)
@@ -202,12 +210,56 @@ struct FusedParams {
   uint32_t kr;      // regenerate only when at least kr lanes are free (or none carries a path)
   uint32_t n_cached;  // four-wide nodes each workgroup copies into LDS (KIND_*_WIDE_HALF)
 };
+// Workgroup scheduler state (LDS).  cursor: low word = next sample index (0..K) of the OPEN tile to hand out, high word =
+// (tile << 5 | slot) of that tile, RT_CUR_NONE before the first tile, RT_CUR_OPENING while a wave opens the next tile,
+// RT_CUR_EXHAUSTED when the frame has no tiles left.
+struct WgSched {
+  unsigned long long cursor;
+  uint32_t pad[2];
+  uint32_t rem[RT_MAX_SLOTS];    // paths of the slot's tile that have not finished yet
+  uint32_t tile[RT_MAX_SLOTS];   // the slot's tile
+  uint32_t state[RT_MAX_SLOTS];  // 0 = free (accumulators zero), 1 = in use
+};
+#define RT_SCHED_BYTES sizeof(WgSched)
+static_assert(sizeof(WgSched) % 16 == 0, "scheduler block keeps the LDS regions 16-byte aligned");
+#define RT_CUR_NONE 0xFFFFFFFEu
+#define RT_CUR_OPENING 0xFFFFFFFDu
+#define RT_CUR_EXHAUSTED 0xFFFFFFFFu
 #define RT_FIX_SCALE 1099511627776.0f  // 2^40
 
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5,
        KIND_GENERIC_WIDE_HALF = 6, KIND_SPHERES_WIDE_HALF = 7 };
 constexpr bool kind_caches_top(int k) { return k == KIND_GENERIC_WIDE_HALF || k == KIND_SPHERES_WIDE_HALF; }
 constexpr bool kind_in_lds(int k) { return k == KIND_SPHERES_LDS || k == KIND_GENERIC_LDS; }
+
+// tile index -> top-left pixel and log2 of the tile's side (all wave-uniform)
+__device__ __forceinline__ void tile_geom(const FusedParams& fp, uint32_t t, uint32_t& x0, uint32_t& y0, uint32_t& shift) {
+  uint32_t lv = 0;
+#pragma unroll
+  for (uint32_t i = 1; i < RT_TILE_LEVELS; i++) lv = t >= fp.lvl_begin[i] ? i : lv;
+  const uint32_t local = t - fp.lvl_begin[lv];
+  shift = fp.lvl_shift[lv];
+  const uint32_t ty = local / fp.lvl_tiles_x[lv], tx = local - ty * fp.lvl_tiles_x[lv];
+  x0 = tx << shift;
+  y0 = fp.lvl_y0[lv] + (ty << shift);
+}
+// sample indices per chunk for a tile of side 1 << shift: a chunk is about Ku x 64 paths whatever the tile's size
+__device__ __forceinline__ uint32_t chunk_samples(const FusedParams& fp, uint32_t shift) { return fp.Ku << (6u - 2u * shift); }
+
+// The scheduler block's LDS address, made opaque at the point of use: the cold scheduling code then forms its per-lane
+// addresses where it runs instead of holding them in VGPRs across the whole render loop (where they get spilled).
+typedef __attribute__((address_space(3))) WgSched LdsSched;
+__device__ __forceinline__ LdsSched* sched_here(WgSched* s) {
+  uint32_t a = (uint32_t)(uintptr_t)(LdsSched*)s;
+  asm volatile("" : "+s"(a));
+  return (LdsSched*)(uintptr_t)a;
+}
+// cursor store (release).  The words are made opaque right here so that the compiler builds the 64-bit value in VGPRs at
+// the (rare) store instead of keeping it in registers across the whole render loop.
+__device__ __forceinline__ void cursor_store(LdsSched* sched, uint32_t hi, uint32_t lo) {
+  asm volatile("" : "+s"(hi), "+s"(lo));
+  __hip_atomic_store(&sched->cursor, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 __device__ __forceinline__ unsigned long long to_fix(float v) {
   if (!(v > 0.f)) return 0ull;  // also NaN
@@ -268,10 +320,17 @@ template <> struct AccOf<KIND_SPHERES_WIDE> {
 // Register budget: 4 waves/SIMD (128 VGPRs) — what a 1024-thread workgroup needs anyway; the 256-thread instances that
 // carry the noise / image / medium code (HBM-resident scenes: C5) run better at 3 waves/SIMD with 168 VGPRs and
 // 272 B of scratch than at 4 with 432 B (26.4 vs 32.6 ms on C5 at 4 spp; 2 waves / 243 VGPRs / no scratch: 30.9).
-template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_TEX_NOISE))) ? 3 : 4) void k_fused(Scene sc, const Camera* __restrict__ camp, FusedParams fp, uint32_t* __restrict__ unit_counter,
-                                                 unsigned long long* __restrict__ fbacc,
-                                                 unsigned long long* __restrict__ ray_total, float* __restrict__ dbg = nullptr) {
+// The lean spheres-in-LDS instance and its 256-thread partner share a CU (4 + 1 waves per SIMD): the partner is held to
+// the 5-waves budget (96 VGPRs), the main instance to 104 (fused_max_vgprs).
+constexpr int fused_waves_per_simd(uint32_t F, int KIND, int BLOCK) {
+  if (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_TEX_NOISE))) return 3;
+  if (F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_WIDE_HALF && BLOCK == 256) return 5;
+  return 4;
+}
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS, bool RESUME>
+__device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __restrict__ camp, const FusedParams& fp, unsigned long long* __restrict__ tile_counter,
+                                           float* __restrict__ out_sum, unsigned long long* __restrict__ ray_total,
+                                           float* __restrict__ dbg) {
   // The camera block (26 doubles) stays in memory: read with scalar loads where a ray is generated instead of
   // occupying ~60 SGPRs for the whole kernel (they spilled to VGPR lanes: 68 v_readlane per regeneration).
   struct { uint32_t width, height, max_depth; } cam = {camp->width, camp->height, camp->max_depth};
@@ -280,7 +339,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
   uint64_t st_t0 = 0, st_tk = 0;
   if (STATS) st_tk = now_cycles();
   extern __shared__ __align__(16) unsigned char smem[];
-  // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [accumulators][stack]
+  // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [scheduler][tile slots][stack]
+  constexpr uint32_t S = BLOCK / 64;  // tile slots of the workgroup
+  static_assert(S <= RT_MAX_SLOTS, "more waves than tile slots");
   size_t off = 0;
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
@@ -307,31 +368,34 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
     uint4* lc = reinterpret_cast<uint4*>(smem);
     for (uint32_t i = threadIdx.x; i < fp.n_cached * 4u; i += BLOCK) lc[i] = sc.nodes4h[i];
   }
-  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off) + (threadIdx.x >> 6) * 192;
-  off += (size_t)(BLOCK / 64) * 192 * 8;
+  WgSched* sched = reinterpret_cast<WgSched*>(smem + off);
+  off += sizeof(WgSched);
+  unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off);  // [slot][pixel][channel]
+  off += (size_t)S * 192 * 8;
   StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
-  if (kind_in_lds(KIND) || kind_caches_top(KIND)) __syncthreads();
+  for (uint32_t i = threadIdx.x; i < S * 192u; i += BLOCK) l_acc[i] = 0;
+  if (threadIdx.x < RT_MAX_SLOTS) { sched->rem[threadIdx.x] = 0; sched->tile[threadIdx.x] = 0; sched->state[threadIdx.x] = threadIdx.x < S ? 0u : 1u; }
+  if (threadIdx.x == 0) sched->cursor = ((unsigned long long)RT_CUR_NONE << 32) | fp.K;  // nothing to hand out yet
+  __syncthreads();
   typename AccOf<KIND>::type acc_init = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
   if constexpr (kind_caches_top(KIND)) acc_init.n_cached = (int32_t)fp.n_cached;
   const typename AccOf<KIND>::type acc = acc_init;
 
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long my_rays = 0;
-  // ---- wave state.  The wave works on one unit (8x8 tile x Ku sample indices) at a time; when the unit's sample pool
-  // is exhausted it moves on to the next unit AT ONCE: the tile's LDS accumulators are flushed, the paths still in
-  // flight become "stragglers" that add their radiance straight to the global frame, and the freed lanes are fed
-  // from the new unit.  Lanes therefore never idle through a unit's drain (up to max_depth bounces of its
-  // longest path) — only through the last one of the wave.
-  uint32_t x0 = 0, y0 = 0, k_lo = 0, total = 0, next = 0;  // wave-uniform: current unit and its pool cursor
-  bool have_unit = false, exhausted = false;               // wave-uniform
-  bool active = false, straggler = false;
+  uint32_t my_rays = 0;
+  // ---- wave state.  The wave works on one chunk (a tile slot x Ku sample indices) at a time; when the chunk's sample pool
+  // is exhausted it claims the next one AT ONCE — of the same tile or, when that is handed out completely, of the next
+  // tile the workgroup opens.  Paths in flight keep accumulating into their own tile's slot, so lanes never idle through
+  // a drain — only through the last one of the workgroup.
+  uint32_t x0 = 0, y0 = 0, c_shift = 3, k_lo = 0, total = 0, next = 0, c_slot = 0;  // wave-uniform: current chunk and its pool cursor
+  bool exhausted = false;                    // wave-uniform: the frame has no more chunks
+  bool opening = false;                      // wave-uniform: this wave has to open the workgroup's next tile
+  bool active = false;
   d3 o = {0, 0, 0}, d = {0, 0, 0};
   double time = 0;
   f3 thr = {1.f, 1.f, 1.f};
-  uint32_t depth = 0, lpix = 0;  // lpix: pixel index inside the tile, or (straggler) 3 * global pixel index
+  uint32_t depth = 0, lpix = 0;  // lpix: slot * 64 + pixel index inside the tile
   PathRng rng = {0, 0};
-  l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
-  __builtin_amdgcn_wave_barrier();
   // RESUME: the lane's traversal progress (node, stack, best hit) survives shade / regenerate rounds of its
   // neighbours; the per-ray constants are recomputed each round (unconditionally, so that they are not live across
   // the shading code)
@@ -340,69 +404,135 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
   bool fresh_lane = false;  // this lane holds a ray whose traversal has not started
   bool fresh = false;       // wave-uniform: some lane received a new ray since the last traversal call
   // shade one finished traversal; returns true when the path continues with a new ray in (o, d)
-  auto bounce = [&](HitInfo hit) -> bool {
+  auto bounce = [&](HitInfo hit, int32_t& flush_slot) -> bool {
     if (STATS) { st_shade += 1.f; st_wshade += wave_share(); st_t0 = now_cycles(); }
     ShadeOut so = shade<F>(sc, acc, *camp, o, d, time, thr, hit, rng);
     if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
-    if (!so.alive) {
+    bool alive = so.alive;
+    if (!alive) {
       const unsigned long long r = to_fix(so.radiance.x), g = to_fix(so.radiance.y), b = to_fix(so.radiance.z);
-      if (straggler) {
-        if (r) atomicAdd(&fbacc[lpix + 0], r);
-        if (g) atomicAdd(&fbacc[lpix + 1], g);
-        if (b) atomicAdd(&fbacc[lpix + 2], b);
-      } else {
-        atomicAdd(&l_acc[lpix * 3 + 0], r);
-        atomicAdd(&l_acc[lpix * 3 + 1], g);
-        atomicAdd(&l_acc[lpix * 3 + 2], b);
-      }
+      if (r) atomicAdd(&l_acc[lpix * 3 + 0], r);
+      if (g) atomicAdd(&l_acc[lpix * 3 + 1], g);
+      if (b) atomicAdd(&l_acc[lpix * 3 + 2], b);
+    } else {
+      depth++;
+      if (depth >= cam.max_depth) alive = false;  // mod.rs:195-197: black
+    }
+    if (!alive) {
+      // one path fewer in flight for its tile.  acq_rel at workgroup scope: the adds above are in LDS before the count
+      // drops, and the lane that takes it to zero sees every other wave's adds.
+      const uint32_t before = __hip_atomic_fetch_sub(&sched->rem[lpix >> 6], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (before == 1u) flush_slot = (int32_t)(lpix >> 6);
       return false;
     }
-    depth++;
-    if (depth >= cam.max_depth) return false;  // mod.rs:195-197: black
     o = so.o; d = so.d; thr = so.thr;
     return true;
   };
-  while (true) {
-    // ---- next unit when the pool is empty
-    if (next >= total && !exhausted) {
-      if (have_unit) {  // flush the finished tile's accumulators; paths still in flight go on as stragglers
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t px = x0 + (lane & 7u), py = y0 + (lane >> 3);
-        if (px < cam.width && py < cam.height) {
-          const size_t p = ((size_t)py * cam.width + px) * 3;
-          const unsigned long long a0 = l_acc[lane * 3], a1 = l_acc[lane * 3 + 1], a2 = l_acc[lane * 3 + 2];
-          if (a0) atomicAdd(&fbacc[p], a0);
-          if (a1) atomicAdd(&fbacc[p + 1], a1);
-          if (a2) atomicAdd(&fbacc[p + 2], a2);
-        }
-        l_acc[lane * 3 + 0] = 0; l_acc[lane * 3 + 1] = 0; l_acc[lane * 3 + 2] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (active && !straggler) {
-          straggler = true;
-          lpix = ((y0 + (lpix >> 3)) * cam.width + x0 + (lpix & 7u)) * 3u;
-        }
+  // tiles whose last path one of this wave's lanes just finished: write the slot to the frame, free it
+  auto flush_finished = [&](int32_t flush_slot) {
+    unsigned long long fm = __ballot(flush_slot >= 0);
+    while (fm) {
+      const int l = __ffsll((long long)fm) - 1;
+      fm &= fm - 1;
+      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane(flush_slot, l);
+      const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched->tile[s]);
+      uint32_t tx0, ty0, tsh;
+      tile_geom(fp, tile, tx0, ty0, tsh);
+      const uint32_t px = tx0 + (lane & ((1u << tsh) - 1u)), py = ty0 + (lane >> tsh);
+      unsigned long long* a = l_acc + s * 192u + lane * 3u;
+      if (lane < (1u << (2u * tsh)) && px < cam.width && py < cam.height) {
+        float* q = out_sum + ((size_t)py * cam.width + px) * 3;
+        q[0] = (float)((double)a[0] * 9.094947017729282e-13);  // 2^-40
+        q[1] = (float)((double)a[1] * 9.094947017729282e-13);
+        q[2] = (float)((double)a[2] * 9.094947017729282e-13);
       }
-      uint32_t u = 0;
-      if (lane == 0) u = atomicAdd(unit_counter, 1u);
-      u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);  // scalar: the unit bookkeeping below stays in SGPRs
-      if (u >= fp.n_units) {
-        exhausted = true;
-        have_unit = false;
-        total = 0; next = 0;
+      a[0] = 0; a[1] = 0; a[2] = 0;
+      if (lane == 0) __hip_atomic_store(&sched->state[s], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  };
+  while (true) {
+    // ---- next chunk when the pool is empty
+    if (next >= total && !exhausted) {
+      LdsSched* const sp = sched_here(sched);
+      total = 0; next = 0;
+      if (opening) {
+        // open the workgroup's next tile in a free slot (none free: every slot still waits for paths in flight — try
+        // again after the next round of work)
+        const uint32_t st = lane < S ? __hip_atomic_load(&sp->state[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 1u;
+        const unsigned long long free_mask = __ballot(st == 0u);
+        if (free_mask) {
+          const uint32_t s = (uint32_t)__ffsll((long long)free_mask) - 1u;
+          // one 64-bit counter for both ends of the tile list (see FusedParams)
+          unsigned long long tc64 = 0;
+          if (lane == 0) {
+            uint32_t back = fp.from_back;
+            asm volatile("" : "+s"(back));  // the increment is built here, not kept in VGPRs across the render loop
+            tc64 = atomicAdd(tile_counter, (unsigned long long)(back ^ 1u) | ((unsigned long long)back << 32));
+          }
+          const uint32_t t_front = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tc64);
+          const uint32_t t_back = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tc64 >> 32));
+          const bool none_left = (unsigned long long)t_front + t_back >= fp.n_tiles;
+          const uint32_t t = fp.from_back ? fp.n_tiles - 1u - t_back : t_front;
+          opening = false;
+          if (none_left) {
+            exhausted = true;
+            if (lane == 0) cursor_store(sp, RT_CUR_EXHAUSTED, fp.K);
+          } else {
+            tile_geom(fp, t, x0, y0, c_shift);
+            const uint32_t side = 1u << c_shift;
+            const uint32_t n_valid = min(side, cam.width - x0) * min(side, cam.height - y0);
+            const uint32_t ks = chunk_samples(fp, c_shift);
+            if (lane == 0) {
+              sp->tile[s] = t;
+              sp->rem[s] = n_valid * fp.K;
+              sp->state[s] = 1u;
+              // the opener keeps the tile's first chunk; release: the slot's words are in LDS before the cursor moves
+              cursor_store(sp, (t << 5) | s, ks);
+            }
+            c_slot = s; k_lo = 0;
+            total = min(ks, fp.K) << (2u * c_shift);
+          }
+        }
       } else {
-        // chunk-major, tiles from the bottom row up: the units that start last are then the top rows, which in the
-        // reference's scenes look at the sky (cheap paths make a short tail)
-        // passes over the tiles, level by level: units get shorter towards the end of the frame (see launch_fused)
-        uint32_t lv = 0;
-#pragma unroll
-        for (uint32_t i = 1; i < RT_UNIT_LEVELS; i++) lv = u >= fp.level_unit0[i] ? i : lv;
-        const uint32_t v = u - fp.level_unit0[lv];
-        const uint32_t tile = v % fp.n_tiles, pass = v / fp.n_tiles;
-        x0 = (tile % fp.tiles_x) * 8; y0 = (tile / fp.tiles_x) * 8;
-        k_lo = fp.level_k0[lv] + pass * fp.level_ku[lv];
-        total = 64u * min(fp.level_ku[lv], fp.K - k_lo);
-        next = 0;
-        have_unit = true;
+        // a chunk of the open tile: look first (no add once the tile is handed out), then claim with one LDS atomic.
+        // The first wave to find the tile handed out completely (or no tile opened yet) takes the duty of opening the
+        // next one: it swaps RT_CUR_OPENING into the cursor — the value it saw is stable, nobody adds to a cursor at or
+        // beyond K except adds already under way, and those make the swap fail harmlessly (next round).
+        unsigned long long c = 0;
+        uint32_t won = 0, inc = 0;
+        if (lane == 0) {
+          c = __hip_atomic_load(&sp->cursor, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t chi = (uint32_t)(c >> 32);
+          if ((uint32_t)c < fp.K) {
+            // the chunk is as long as what this wave adds (sized for the tile it saw; another tile may have been opened
+            // in between: then the chunk is merely longer or shorter than that tile's usual ones)
+            uint32_t gx, gy, gs;
+            tile_geom(fp, chi >> 5, gx, gy, gs);
+            inc = chunk_samples(fp, gs);
+            c = __hip_atomic_fetch_add(&sp->cursor, (unsigned long long)inc, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else if (chi != RT_CUR_EXHAUSTED && chi != RT_CUR_OPENING) {
+            unsigned long long expect = c;
+            uint32_t want_hi = RT_CUR_OPENING, want_lo = fp.K;
+            asm volatile("" : "+s"(want_hi), "+s"(want_lo));  // built here, not hoisted out of the render loop
+            won = __hip_atomic_compare_exchange_strong(&sp->cursor, &expect, ((unsigned long long)want_hi << 32) | want_lo,
+                                                       __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+          }
+        }
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c >> 32));
+        won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+        inc = (uint32_t)__builtin_amdgcn_readfirstlane((int)inc);
+        if (k < fp.K) {
+          c_slot = hi & 31u;
+          tile_geom(fp, hi >> 5, x0, y0, c_shift);
+          k_lo = k;
+          total = min(inc, fp.K - k) << (2u * c_shift);
+        } else if (hi == RT_CUR_EXHAUSTED) {
+          exhausted = true;
+        } else if (won) {
+          opening = true;
+          continue;
+        }
       }
     }
     // ---- regenerate: lanes without a path take the next samples of the pool (wave64 ballot + prefix)
@@ -412,8 +542,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
     if (n_free && (n_free >= fp.kr || n_free == 64u) && next < total) {
       uint32_t j = next + wave_prefix(need);
       if (!active && j < total) {
-        uint32_t pit = j & 63u, ks = j >> 6;
-        uint32_t px = x0 + (pit & 7u), py = y0 + (pit >> 3);
+        const uint32_t pit = j & ((1u << (2u * c_shift)) - 1u), ks = j >> (2u * c_shift);
+        const uint32_t px = x0 + (pit & ((1u << c_shift) - 1u)), py = y0 + (pit >> c_shift);
         if (px < cam.width && py < cam.height) {
           if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
           uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
@@ -422,8 +552,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
           generate_ray(*cp, py, px, s, fp.k0, fp.k1, o, d, time, rng);
           thr = {1.f, 1.f, 1.f};
           depth = 0;
-          lpix = pit;
-          straggler = false;
+          lpix = c_slot * 64u + pit;
           active = true;
           fresh_lane = true;
         }
@@ -434,6 +563,30 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
     if (STATS) st_tregen += (float)(now_cycles() - st_t0) * wave_share();
     if (__ballot(active) == 0ull) {
       if (exhausted) break;
+      if (next >= total) {
+        // Nothing to hand out right now: another wave is opening the next tile, or (this wave being the opener) every
+        // slot still waits for paths in flight.  Poll until that changes.  Safety valve: after ~10 s of polling the
+        // wave gives up and flags the frame as failed (tile_counter[1], reported by rt_get_stats) rather than hang the
+        // GPU on a scheduling bug.
+        LdsSched* const sp = sched_here(sched);
+        bool go = false;
+        uint32_t polls = 0;
+        do {
+          __builtin_amdgcn_s_sleep(8);
+          if (opening) {
+            const uint32_t st = lane < S ? __hip_atomic_load(&sp->state[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) : 1u;
+            go = __ballot(st == 0u) != 0ull;
+          } else {
+            uint32_t chi = 0;
+            if (lane == 0) chi = (uint32_t)(__hip_atomic_load(&sp->cursor, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+            go = (uint32_t)__builtin_amdgcn_readfirstlane((int)chi) != RT_CUR_OPENING;
+          }
+        } while (!go && ++polls < (1u << 24));
+        if (!go) {
+          if (lane == 0) atomicOr(reinterpret_cast<uint32_t*>(tile_counter + 1), 1u);
+          break;
+        }
+      }
       continue;
     }
     if (RESUME) {
@@ -450,24 +603,31 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
       t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
       const bool ready = active && t_cur == RT_DONE;
       fresh = __ballot(ready) != 0ull;
+      int32_t flush_slot = -1;  // this lane finished the last path of that slot's tile
       if (ready) {
         HitInfo hit;
         hit.t = t_best_t;
         hit.prim = t_best_prim;
-        if (bounce(hit)) fresh_lane = true;
+        if (bounce(hit, flush_slot)) fresh_lane = true;
         else active = false;
       }
-    } else if (active) {
+      flush_finished(flush_slot);
+    } else {
       // ---- one bounce for every lane that carries a path: closest hit, then shade
-      my_rays++;
-      HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
-                                                                        stack, BLOCK, &tc, rng);
-      if (!bounce(hit)) active = false;
+      int32_t flush_slot = -1;
+      if (active) {
+        my_rays++;
+        HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
+                                                                          stack, BLOCK, &tc, rng);
+        if (!bounce(hit, flush_slot)) active = false;
+      }
+      flush_finished(flush_slot);
     }
   }
   // rays traced (stats): one atomic per wave
-  for (int off2 = 32; off2 > 0; off2 >>= 1) my_rays += __shfl_down(my_rays, off2, 64);
-  if (lane == 0 && my_rays) atomicAdd(ray_total, my_rays);
+  unsigned long long wave_rays = my_rays;
+  for (int off2 = 32; off2 > 0; off2 >>= 1) wave_rays += __shfl_down(wave_rays, off2, 64);
+  if (lane == 0 && wave_rays) atomicAdd(ray_total, wave_rays);
   if (STATS && dbg) {  // diagnostic build only: lane-work vs wave-trip tallies per phase
     st_ttotal = (float)(now_cycles() - st_tk) * (1.0f / 64.0f);
     float v[13] = {(float)tc.nodes, tc.wnodes, (float)tc.prims, tc.wprims, st_shade, st_wshade, st_regen, st_wregen,
@@ -482,11 +642,31 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_
   }
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_fix_to_float(const unsigned long long* __restrict__ acc, float* __restrict__ fb,
-                                                           uint32_t n) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    fb[i] = (float)((double)acc[i] * 9.094947017729282e-13);  // 2^-40
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
+__global__ __launch_bounds__(BLOCK, fused_waves_per_simd(F, KIND, BLOCK)) void k_fused(Scene sc, const Camera* __restrict__ camp, FusedParams fp,
+                                                                                       unsigned long long* __restrict__ tile_counter, float* __restrict__ out_sum,
+                                                                                       unsigned long long* __restrict__ ray_total,
+                                                                                       float* __restrict__ dbg = nullptr) {
+  fused_body<F, KIND, BLOCK, StackT, STATS, RESUME>(sc, camp, fp, tile_counter, out_sum, ray_total, dbg);
+}
+// The lean spheres-in-LDS instance (C1 / C2) with its own register ceiling: 4 x 104 VGPRs + the partner's 96 = 512, the
+// SIMD's register file (the attribute takes no template-dependent value, hence a kernel of its own).
+// (this compiler doubles the attribute's value on gfx950's unified register file: 52 caps the kernel at 104 VGPRs)
+#ifndef RT_LEAN_VGPR_ATTR
+#define RT_LEAN_VGPR_ATTR 52
+#endif
+template <bool STATS, bool RESUME>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(RT_LEAN_VGPR_ATTR))) void k_fused_lean(Scene sc, const Camera* __restrict__ camp, FusedParams fp,
+                                                                                            unsigned long long* __restrict__ tile_counter, float* __restrict__ out_sum,
+                                                                                            unsigned long long* __restrict__ ray_total,
+                                                                                            float* __restrict__ dbg = nullptr) {
+  fused_body<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, STATS, RESUME>(sc, camp, fp, tile_counter, out_sum, ray_total, dbg);
+}
+typedef void (*FusedKernel)(Scene, const Camera*, FusedParams, unsigned long long*, float*, unsigned long long*, float*);
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS, bool RESUME>
+static FusedKernel fused_kernel() {
+  if constexpr (F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && sizeof(StackT) == 2) return k_fused_lean<STATS, RESUME>;
+  else return k_fused<F, KIND, BLOCK, StackT, STATS, RESUME>;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ sum, uint32_t n_values, double inv_spp,
@@ -594,7 +774,7 @@ struct WorkBuffers {
 // Device memory a fused render needs beyond its inputs and outputs.
 struct FrameScratch {
   unsigned long long* fbacc = nullptr;      // W*H*3 fixed-point frame accumulators
-  uint32_t* unit_counter = nullptr;         // work-unit counter of the persistent kernel
+  unsigned long long* unit_counter = nullptr;  // [0] two-ended tile counter of the persistent kernel, [1] its watchdog flag
   Camera* cam = nullptr;                    // camera block of the render in flight (read with scalar loads)
   unsigned long long* ray_total = nullptr;  // rays traced (stats)
 };
@@ -612,7 +792,11 @@ struct rt_ctx {
   int fused_kr = 16;
   std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
   std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
-  int fused_tail = 4, fused_tail_ku = 0;  // the last passes' worth of samples goes out in shorter units (launch_fused)
+  int fused_partner_min = 8;  // partner workgroups only for frames of at least this many Mi samples
+  int fused_tail4 = 50, fused_tail2 = 30;  // share of the frame's rows (per mille) tiled 4x4 / 2x2 at the end of the tile list
+  float* cur_out = nullptr;   // output frame of the render being issued
+  bool cur_partner = false;   // ... and whether partner workgroups join it
+  int dbg_main_cap = 0;       // diagnostic: cap on the main kernel's workgroups (0 = none)
   int fused_partner = 1;  // C1/C2-class scenes: a 256-thread workgroup per CU beside the 1024-thread one (fifth wave per SIMD)
   hipStream_t partner_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -627,6 +811,7 @@ struct rt_ctx {
   FrameScratch own, fixed;
   const FrameScratch* fs = &own;
   const unsigned long long* last_ray_total = nullptr;  // ray counter of the last render (rt_get_stats)
+  const uint32_t* last_watchdog = nullptr;             // watchdog flag of the last fused render
   size_t fbacc_cap = 0;
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
   unsigned long long probe_rays = 0;
@@ -726,7 +911,7 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->own.ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->own.unit_counter, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->own.unit_counter, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->own.cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->own.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   ctx->last_ray_total = ctx->own.ray_total;
@@ -740,7 +925,7 @@ int rt_init(int device_id, rt_ctx** out) {
     unsigned char* ctl = b + (size_t)RT_NOALLOC_MAX_PIXELS * 3 * 8;
     ctx->fixed.cam = reinterpret_cast<Camera*>(ctl);
     ctx->fixed.ray_total = reinterpret_cast<unsigned long long*>(ctl + 512);
-    ctx->fixed.unit_counter = reinterpret_cast<uint32_t*>(ctl + 768);
+    ctx->fixed.unit_counter = reinterpret_cast<unsigned long long*>(ctl + 768);
   }
   // the partner workgroups' stream and fork / join events (launch_partner): created here so that no render call has to
   if ((e = hipStreamCreateWithFlags(&ctx->partner_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -823,9 +1008,14 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "probe_tree") {
     if (value < 0 || value > 2) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be 0, 1 or 2");
     ctx->probe_tree = (int)value;
-  } else if (k == "fused_tail" || k == "fused_tail_ku") {
-    if (value < 0 || value > 64) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 0..64");
-    (k == "fused_tail" ? ctx->fused_tail : ctx->fused_tail_ku) = (int)value;
+  } else if (k == "fused_tail4" || k == "fused_tail2") {
+    if (value < 0 || value > 400) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 0..400 (per mille of the frame's rows)");
+    (k == "fused_tail4" ? ctx->fused_tail4 : ctx->fused_tail2) = (int)value;
+  } else if (k == "dbg_main_cap") {
+    ctx->dbg_main_cap = (int)std::max<int64_t>(0, std::min<int64_t>(value, 65536));
+  } else if (k == "fused_partner_min") {
+    if (value < 0 || value > 65536) return fail(ctx, RT_E_INVALID_ARG, "fused_partner_min out of range");
+    ctx->fused_partner_min = (int)value;
   } else if (k == "fused_partner") {
     ctx->fused_partner = value ? 1 : 0;
   } else if (k == "fused_half") {
@@ -1356,18 +1546,30 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 // at 96 VGPRs, 134 KB of LDS at C2 — a fifth wave per SIMD has registers (512 - 4 x 96 = 128) but no room for a
 // second copy of the scene.  The partner is a 256-thread workgroup per CU of the instance that needs no copy: the
 // four-wide binary16 tree in whatever LDS is left (all or most of its 15 KB at C2), sphere records through L1/L2.
-// It runs on a second stream, pulls work units from the same counter and adds into the same frame accumulator.
+// It runs on a second stream and takes its tiles from the same counter.
+// Samples per chunk (what a wave claims from its workgroup's open tile at a time): about one chunk per wave and tile,
+// at most 8 sample indices (512 paths), unless overridden (option fused_ku).  Never changes the frame.
+// (C2, 100 spp: 2 -> 9.67 ms, 3 -> 9.75, 6 -> 9.53, 8 -> 9.62, 12 -> 9.63, 16 -> 9.84, 25 -> 10.97; 13 spp: 1-2 best)
+static uint32_t fused_chunk(const rt_ctx* ctx, uint32_t K, uint32_t waves) {
+  if (ctx->fused_ku > 0) return (uint32_t)std::min<int64_t>(ctx->fused_ku, std::max<uint32_t>(K, 1u));
+  return std::max<uint32_t>(1u, std::min<uint32_t>(8u, K / waves));
+}
+// LDS is allocated in granules of 1280 bytes on gfx950 (160 KiB / 128): two workgroups share a CU only if their ROUNDED
+// sizes fit together (measured: 134 432 + 28 368 B = 162 800 B did not co-reside, 134 224 + 28 592 B did).
+static size_t lds_round(size_t bytes) { return (bytes + 1279) / 1280 * 1280; }
 static bool partner_possible(const rt_ctx* ctx, const rt_scene* scene, size_t lds_main) {
   if (!ctx->fused_partner || !scene->half_ok || scene->view.n_nodes4 >= 32768 || scene->view.n_prims >= 32768) return false;
-  const size_t fixed = 4 * 192 * 8 + (size_t)(scene->wide_stack + 2) * 256 * 2;
-  return lds_main + fixed + 16 * 64 + 1024 <= 160 * 1024;
+  const size_t fixed = RT_SCHED_BYTES + 4 * 192 * 8 + (size_t)(scene->wide_stack + 2) * 256 * 2;
+  return lds_round(lds_main) + lds_round(fixed + 16 * 64) <= 160 * 1024;
 }
 static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams& fp_main, size_t lds_main, hipStream_t st) {
-  auto kern = k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true>;
-  FusedParams fp = fp_main;  // same work units
+  const FusedKernel kern = k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true>;
+  FusedParams fp = fp_main;  // same frame, same tile counter — taken from the other end
+  fp.from_back = 1;
+  fp.Ku = fused_chunk(ctx, fp.K, 4);
   fp.stack_depth = (uint32_t)scene->wide_stack + 2u;
-  const size_t fixed = 4 * 192 * 8 + (size_t)fp.stack_depth * 256 * 2;
-  const size_t room = 160 * 1024 - lds_main - 1024;  // allocation granularity
+  const size_t fixed = RT_SCHED_BYTES + 4 * 192 * 8 + (size_t)fp.stack_depth * 256 * 2;
+  const size_t room = 160 * 1024 - lds_round(lds_main);  // what the main workgroup leaves on its CU (a multiple of the granule)
   fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (room - fixed) / 64);
   const size_t smem = fixed + (size_t)fp.n_cached * 64;
   size_t& opted = ctx->fused_lds_opt_in[reinterpret_cast<const void*>(kern)];
@@ -1375,9 +1577,10 @@ static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams&
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     opted = smem;
   }
+  if (getenv("RT_VERBOSE")) fprintf(stderr, "[rt] partner: LDS %zu B (main %zu B), %u cached nodes of %d, stack %u\n", smem, lds_main, fp.n_cached, scene->view.n_nodes4, fp.stack_depth);
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->partner_stream, ctx->ev_fork, 0));
   hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->n_cu), dim3(256), smem, ctx->partner_stream, scene->view, ctx->fs->cam, fp,
-                     ctx->fs->unit_counter, ctx->fs->fbacc, ctx->fs->ray_total, (float*)nullptr);
+                     ctx->fs->unit_counter, ctx->cur_out, ctx->fs->ray_total, (float*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->partner_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -1386,7 +1589,7 @@ static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams&
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
-  auto kern = k_fused<F, KIND, BLOCK, StackT, STATS, RESUME>;
+  const FusedKernel kern = fused_kernel<F, KIND, BLOCK, StackT, STATS, RESUME>();
   // the LDS opt-in and the occupancy query cost tens of microseconds of host time: once per (instance, LDS size)
   const std::pair<const void*, size_t> key(reinterpret_cast<const void*>(kern), smem);
   auto cached = ctx->fused_occupancy.find(key);
@@ -1402,60 +1605,19 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   }
   const int per_cu = cached->second;
   if (per_cu < 1) return fail(ctx, RT_E_INTERNAL, "fused kernel does not fit on a CU");
-  const uint32_t waves = (uint32_t)ctx->n_cu * (uint32_t)per_cu * (BLOCK / 64);
   FusedParams fp = fp0;
-  // work-unit size: ~48 units per resident wave for load balance at the end of the frame (a wave switches units
-  // without draining, so small units cost only their flush), unless overridden
-  uint32_t chunks = 1;
-  if (ctx->fused_ku > 0) {
-    chunks = (fp.K + (uint32_t)ctx->fused_ku - 1) / (uint32_t)ctx->fused_ku;
-  } else {
-    uint64_t target = (uint64_t)waves * 48;
-    chunks = (uint32_t)std::min<uint64_t>(fp.K, std::max<uint64_t>(1, target / fp.n_tiles));
-  }
-  fp.Ku = (fp.K + chunks - 1) / chunks;
-  chunks = (fp.K + fp.Ku - 1) / fp.Ku;
-  // The frame ends when the last wave ends.  Unit costs spread widely (a tile of glass spheres takes 5-7 times the
-  // average), and a costly unit that starts in the last pass over the tiles overruns all the others by most of its
-  // length.  So units get shorter towards the end of the frame: with many passes over the tiles (C2: 15 of 7
-  // samples) all but the last `fused_tail` (4) go out at full size and the rest in units of `fused_tail_ku` samples
-  // (0 = half): -2.5 % on C2; single-sample units cost more than they save (+1 %).  With a single pass (C5 at 4K:
-  // the tiles alone are units enough) halving sizes K/2, K/4, ... bought nothing (54.3 vs 53.9 ms) and are not used.
-  // The schedule never changes the frame (a sample's key is its index, sums are integers).
-  struct Level { uint32_t k0, ku, passes; } lv[RT_UNIT_LEVELS];
-  int n_lv = 0;
-  const uint32_t kt = ctx->fused_tail_ku > 0 ? (uint32_t)ctx->fused_tail_ku : (fp.Ku + 1) / 2;
-  if (ctx->fused_tail > 0 && chunks >= 4 && kt < fp.Ku) {
-    const uint32_t main_chunks = chunks - std::min<uint32_t>((uint32_t)ctx->fused_tail, chunks - 1);
-    const uint32_t k_tail = main_chunks * fp.Ku;
-    lv[n_lv++] = {0u, fp.Ku, main_chunks};
-    lv[n_lv++] = {k_tail, kt, (fp.K - k_tail + kt - 1) / kt};
-  } else {
-    lv[n_lv++] = {0u, fp.Ku, chunks};
-  }
-  uint64_t unit0 = 0;
-  for (int i = 0; i < RT_UNIT_LEVELS; i++) {
-    if (i < n_lv) {
-      fp.level_unit0[i] = (uint32_t)unit0; fp.level_k0[i] = lv[i].k0; fp.level_ku[i] = lv[i].ku;
-      unit0 += (uint64_t)fp.n_tiles * lv[i].passes;
-      if (unit0 >= 0xFFFFFFFFull) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: more work units than the 32-bit unit counter holds (raise fused_ku)");
-    } else {
-      fp.level_unit0[i] = 0xFFFFFFFFu; fp.level_k0[i] = fp.K; fp.level_ku[i] = 1;
-    }
-  }
-  fp.n_units = (uint32_t)unit0;
-  const uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, (fp.n_units + BLOCK / 64 - 1) / (BLOCK / 64));
+  fp.Ku = fused_chunk(ctx, fp.K, BLOCK / 64);
+  uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, fp.n_tiles);
+  if (ctx->dbg_main_cap > 0) blocks = std::min<uint32_t>(blocks, (uint32_t)ctx->dbg_main_cap);  // diagnostic
   // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
   // buffer has to outlive an asynchronous copy
   hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->fs->cam);
   constexpr bool kHasPartner = F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && RESUME && !STATS;
-  // (a frame of under ~8 M samples is over in well under a millisecond: the second launch and its join cost more there)
-  const bool partner = kHasPartner && per_cu == 1 && (uint64_t)fp.n_tiles * 64u * fp.K >= (8ull << 20) &&
-                       partner_possible(ctx, scene, smem);
+  const bool partner = kHasPartner && per_cu == 1 && ctx->cur_partner;  // decided by render_fused (it shapes the tile list)
   if (partner) {
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));  // frame cleared, counter reset, camera stored
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));  // counter reset, camera stored
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->fs->cam, fp, ctx->fs->unit_counter, ctx->fs->fbacc,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, st, scene->view, ctx->fs->cam, fp, ctx->fs->unit_counter, ctx->cur_out,
                      ctx->fs->ray_total, ctx->d_dbg);
   HIP_TRY(ctx, hipGetLastError());
   if (partner) return launch_partner(ctx, scene, fp, smem, st);
@@ -1478,22 +1640,12 @@ static int launch_variant(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, 
 
 static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const Camera& dc, uint64_t seed,
                         uint32_t sample_begin, uint32_t sample_stride, uint32_t K, float* d_out_sum, hipStream_t st) {
-  const size_t n_val = (size_t)cam->width * cam->height * 3;
-  if (ctx->fs == &ctx->own && ctx->fbacc_cap < n_val) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->own.fbacc) (void)hipFree(ctx->own.fbacc);
-    ctx->own.fbacc = nullptr;
-    ctx->fbacc_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->own.fbacc, n_val * 8));
-    ctx->fbacc_cap = n_val;
-  }
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->fbacc, 0, n_val * 8, st));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->unit_counter, 0, sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->unit_counter, 0, 2 * sizeof(unsigned long long), st));  // [0] tile counter, [1] watchdog flag
+  ctx->cur_out = d_out_sum;
+  ctx->last_watchdog = reinterpret_cast<const uint32_t*>(ctx->fs->unit_counter + 1);
   FusedParams fp;
   memset(&fp, 0, sizeof(fp));
   fp.K = K; fp.s_begin = sample_begin; fp.s_stride = sample_stride;
-  fp.tiles_x = (cam->width + 7) / 8;
-  fp.n_tiles = fp.tiles_x * ((cam->height + 7) / 8);
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
@@ -1507,9 +1659,43 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.noise_lds = lds_noise ? 1u : 0u;
   const size_t lds_tables = lds_noise;  // material / texture records stay in HBM/L2: LDS copies bought nothing measurable
   const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64 + lds_tables;
-  const size_t lds_1024 = lds_scene + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
+  const size_t lds_1024 = lds_scene + RT_SCHED_BYTES + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
   const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_tables +
-                                  16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
+                                  RT_SCHED_BYTES + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
+  // partner workgroups (launch_partner) join the lean spheres-in-LDS instance on frames that last long enough for a
+  // second launch and its join to pay (option fused_partner_min, Mi samples)
+  ctx->cur_partner = ctx->fused_partner && lean && !ctx->fused_stats && scene->spheres_only && ctx->fused_lds && small_ids &&
+                     lds_1024 <= 160 * 1024 && use_resume(ctx, scene) &&
+                     (uint64_t)cam->width * cam->height * K >= ((uint64_t)ctx->fused_partner_min << 20) &&
+                     (uint64_t)cam->width * cam->height >= 64ull * 4 * (uint64_t)ctx->n_cu && partner_possible(ctx, scene, lds_1024);
+  {
+    // Tile list (FusedParams): 8x8 tiles for most of the frame, then two short bands of small tiles.  A small tile must
+    // still be worth opening (>= ~200 paths): 4x4 from 12 samples per pixel on, 2x2 from 48.  Band heights in tile rows
+    // of 8 pixels: options fused_tail4 / fused_tail2 (per mille of the frame's rows; defaults 50 / 30).
+    const uint32_t rows8 = (cam->height + 7) / 8;
+    // (with partner workgroups the 4x4 band is what they render — about a tenth of the frame at C2 — hence 3x as tall)
+    const uint32_t pm4 = (uint32_t)ctx->fused_tail4 * (ctx->cur_partner ? 3u : 1u);
+    uint32_t r4 = K >= 12 ? (rows8 * pm4 + 500) / 1000 : 0;
+    uint32_t r2 = K >= 48 ? (rows8 * (uint32_t)ctx->fused_tail2 + 500) / 1000 : 0;
+    if (r4 + r2 >= rows8) { r4 = 0; r2 = 0; }
+    // list order: with partner workgroups (they take tiles from the END of the list, four waves to a tile) the 4x4 band
+    // is last and the 2x2 band in the middle, where the two kinds of workgroup meet; otherwise sizes simply decrease
+    const bool back_is_4 = ctx->cur_partner;
+    const uint32_t shifts[3] = {3u, back_is_4 ? 1u : 2u, back_is_4 ? 2u : 1u};
+    const uint32_t band_rows8[3] = {rows8 - r4 - r2, back_is_4 ? r2 : r4, back_is_4 ? r4 : r2};
+    uint32_t y = 0, t = 0;
+    for (int i = 0; i < RT_TILE_LEVELS; i++) {
+      const uint32_t y_end = std::min<uint32_t>(cam->height, y + band_rows8[i] * 8u);
+      const uint32_t side = 1u << shifts[i];
+      fp.lvl_begin[i] = t; fp.lvl_y0[i] = y; fp.lvl_shift[i] = shifts[i];
+      fp.lvl_tiles_x[i] = (cam->width + side - 1) / side;
+      t += fp.lvl_tiles_x[i] * ((y_end - y + side - 1) / side);
+      y = y_end;
+    }
+    fp.lvl_begin[RT_TILE_LEVELS] = t;
+    fp.n_tiles = t;
+    fp.from_back = 0;
+  }
   StageTimer tm(ctx, st);
   tm.begin();
   if (ctx->fused_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
@@ -1529,7 +1715,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     const bool wide = ctx->fused_wide != 0;
     const uint32_t sd = wide ? (uint32_t)scene->wide_stack + 2u : sdepth;
     fp.stack_depth = sd;
-    const size_t smem = 4 * 192 * 8 + (size_t)sd * 256 * 4;
+    const size_t smem = RT_SCHED_BYTES + 4 * 192 * 8 + (size_t)sd * 256 * 4;
     if (smem > 160 * 1024) return fail(ctx, RT_E_INTERNAL, "traversal stack does not fit in LDS");
 #define RT_GLOBAL_DISPATCH(KS, KG)                                                                                              \
     if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KS, 256, int32_t>(ctx, scene, dc, fp, smem, st);       \
@@ -1544,7 +1730,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     // for the instances with the noise code, 1024 otherwise.
     const bool heavy = !(scene->spheres_only && lean);  // instances compiled with RT_F_TEX_NOISE
     const uint32_t cblock = heavy ? 768u : 1024u;
-    const size_t cfixed = (size_t)(cblock / 64) * 192 * 8 + (size_t)sd * cblock * 2;
+    const size_t cfixed = RT_SCHED_BYTES + (size_t)(cblock / 64) * 192 * 8 + (size_t)sd * cblock * 2;
     const bool ids16 = scene->view.n_nodes4 < 32768 && scene->view.n_prims < 32768;
     if (wide && ctx->fused_half && scene->half_ok && ids16 && cfixed + 16 * 64 <= 160 * 1024) {
       fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (160 * 1024 - cfixed) / 64);
@@ -1561,9 +1747,6 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   }
   if (rc) return rc;
   tm.end(ctx->stats.ms_intersect);
-  const uint32_t blocks = std::min<uint32_t>((uint32_t)((n_val + RT_BLOCK - 1) / RT_BLOCK), (uint32_t)ctx->n_cu * 8);
-  hipLaunchKernelGGL(k_fix_to_float, dim3(blocks), dim3(RT_BLOCK), 0, st, ctx->fs->fbacc, d_out_sum, (uint32_t)n_val);
-  HIP_TRY(ctx, hipGetLastError());
   ctx->stats.passes = 1;
   return RT_OK;
 }
@@ -1599,6 +1782,7 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* scene, const rt_camer
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
   HIP_TRY(ctx, hipMemsetAsync(ctx->fs->ray_total, 0, sizeof(unsigned long long), st));
   ctx->last_ray_total = ctx->fs->ray_total;
+  ctx->last_watchdog = nullptr;
   if (K > 0 && cam->max_depth > 0) {
     ctx->stats.paths = (uint64_t)n_pix * K;
     if (ctx->mode == 0) {
@@ -1658,7 +1842,17 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     unsigned long long rays = 0;
     HIP_TRY(ctx, hipMemcpy(&rays, ctx->last_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
     ctx->stats.rays = rays;
-    HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 14 * sizeof(float), hipMemcpyDeviceToHost));
+    if (ctx->last_watchdog) {
+      // tiles the main workgroups took from the front of the list / the partner workgroups from its end (diagnostic)
+      uint32_t taken[2] = {0, 0};
+      HIP_TRY(ctx, hipMemcpy(taken, ctx->last_watchdog - 2, sizeof(taken), hipMemcpyDeviceToHost));
+      ctx->stats.dbg[14] = (float)taken[0];
+      ctx->stats.dbg[15] = (float)taken[1];
+      uint32_t flag = 0;
+      HIP_TRY(ctx, hipMemcpy(&flag, ctx->last_watchdog, sizeof(flag), hipMemcpyDeviceToHost));
+      if (flag) return fail(ctx, RT_E_INTERNAL, "fused kernel: a wave found no work for seconds and gave up (scheduler watchdog); the frame is incomplete");
+    }
     unsigned long long trav[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpy(trav, ctx->d_trav, sizeof(trav), hipMemcpyDeviceToHost));
     ctx->stats.probe_rays = ctx->probe_rays;

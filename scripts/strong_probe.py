@@ -31,3 +31,5 @@ for n in (1, 2, 4, 8):
 for n in res:
     res[n]["efficiency"] = res[1]["ms"] / n / res[n]["ms"]
 print(json.dumps(res))
+st = ctx.stats()
+print("tiles taken at the front / back of the list in the last frame:", st["dbg"][14], st["dbg"][15])
