@@ -161,11 +161,15 @@ __device__ __forceinline__ f3 normalize(f3 a) {
 // |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
 // coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
 #define RT_SLAB_WIDEN 1.0000019f  // exit distances are widened by 16 ulp (+1e-30) before the entry <= exit test
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SlabRay {
-  float ix, iy, iz;     // 1/d
-  float nx, ny, nz;     // o/d widened towards later entry ... subtracted from plane/d for entry planes
-  float ixw, iyw, izw;  // (1/d) * RT_SLAB_WIDEN: exit planes carry the widening factor in their multiplier
-  float fx, fy, fz;     // (o/d widened towards earlier exit) * RT_SLAB_WIDEN - 1e-30
+  // Per axis two register PAIRS, laid out for v_pk_fma_f32 (two f32 FMAs per issue slot — the packed form is what the
+  // 157 TFLOP/s vector peak is made of; plain v_fma_f32 runs at half of it):
+  //   m = {1/d, (1/d) * RT_SLAB_WIDEN}: multiplier of the entry planes / of the exit planes (widening folded in)
+  //   a = {o/d widened towards later entry, (o/d widened towards earlier exit) * RT_SLAB_WIDEN - 1e-30}: what is
+  //       subtracted from plane * multiplier for entry / exit planes
+  f32x2 mx, my, mz;
+  f32x2 ax, ay, az;
   bool sx, sy, sz;       // direction negative on axis (select-based node fetch: GlobalAcc / SphereAcc)
   uint32_t ox, oy, oz;   // byte offset of the ray's direction-ordered plane quad inside a slab node (SlabLdsAcc)
 };
@@ -174,17 +178,17 @@ struct SlabRay {
 __device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
   SlabRay s;
   float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-  s.ix = __builtin_amdgcn_rcpf((float)d.x);
-  s.iy = __builtin_amdgcn_rcpf((float)d.y);
-  s.iz = __builtin_amdgcn_rcpf((float)d.z);
-  float ax = ox * s.ix, ay = oy * s.iy, az = oz * s.iz;
+  const float ix = __builtin_amdgcn_rcpf((float)d.x);
+  const float iy = __builtin_amdgcn_rcpf((float)d.y);
+  const float iz = __builtin_amdgcn_rcpf((float)d.z);
+  float ax = ox * ix, ay = oy * iy, az = oz * iz;
   const float E = 9.5367431640625e-07f;  // 2^-20: > 8 ulp, covers o / d / rcp / fma rounding
   float ex = __builtin_fabsf(ax) * E, ey = __builtin_fabsf(ay) * E, ez = __builtin_fabsf(az) * E;
-  s.nx = ax + ex; s.ny = ay + ey; s.nz = az + ez;
-  s.ixw = s.ix * RT_SLAB_WIDEN; s.iyw = s.iy * RT_SLAB_WIDEN; s.izw = s.iz * RT_SLAB_WIDEN;
-  s.fx = (ax - ex) * RT_SLAB_WIDEN - 1e-30f; s.fy = (ay - ey) * RT_SLAB_WIDEN - 1e-30f;
-  s.fz = (az - ez) * RT_SLAB_WIDEN - 1e-30f;
-  s.sx = s.ix < 0.f; s.sy = s.iy < 0.f; s.sz = s.iz < 0.f;
+  s.mx = {ix, ix * RT_SLAB_WIDEN}; s.my = {iy, iy * RT_SLAB_WIDEN}; s.mz = {iz, iz * RT_SLAB_WIDEN};
+  s.ax = {ax + ex, (ax - ex) * RT_SLAB_WIDEN - 1e-30f};
+  s.ay = {ay + ey, (ay - ey) * RT_SLAB_WIDEN - 1e-30f};
+  s.az = {az + ez, (az - ez) * RT_SLAB_WIDEN - 1e-30f};
+  s.sx = ix < 0.f; s.sy = iy < 0.f; s.sz = iz < 0.f;
   s.ox = s.sx ? 16u : 0u; s.oy = s.sy ? 48u : 32u; s.oz = s.sz ? 80u : 64u;
   return s;
 }
@@ -192,19 +196,37 @@ __device__ __forceinline__ SlabRay make_slab(d3 o, d3 d) {
 // already ordered for the ray's direction.  tl / tr: entry distances clamped to 0; hit iff entry <= widened exit.
 // The widening (x RT_SLAB_WIDEN + 1e-30) is folded into the exit planes' per-ray constants and into `tmax_w`
 // (= tmax * RT_SLAB_WIDEN + 1e-30, kept by the caller): min(a, b) * K + c == min(a * K + c, b * K + c) for K > 0.
-// fmaxf/fminf ignore NaN (0*inf axes) => conservative.
+// v_max / v_min ignore a quiet NaN operand (0*inf axes) => conservative.
+// {p.x * m.x - a.x, p.y * m.x - a.x}: two planes against the ENTRY constants (low halves of m and a, broadcast by
+// op_sel).  Written as asm because the compiler, given the same thing as a vector fma of splats, hoists the four splats
+// per axis out of the traversal loop as register pairs of their own (24 VGPRs of ray constants instead of 12).
+__device__ __forceinline__ f32x2 pk_planes_entry(f32x2 p, f32x2 m, f32x2 a) {
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(p), "v"(m), "v"(a));
+  return r;
+}
+// {p.x * m.y - a.y, p.y * m.y - a.y}: two planes against the EXIT constants (high halves of m and a, broadcast)
+__device__ __forceinline__ f32x2 pk_planes_exit(f32x2 p, f32x2 m, f32x2 a) {
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(p), "v"(m), "v"(a));
+  return r;
+}
+// min / max of plane distances, NaN-ignoring like fminf / fmaxf (the only NaNs here are the quiet ones of 0 * inf).
+// Also asm: on the output of an asm statement the compiler would first canonicalise every operand (v_max_f32 x, x, x).
+__device__ __forceinline__ float slab_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float slab_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float slab_max3_zero(float a, float b) { float r; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float slab_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ void slab_pair_test(const SlabRay& s, float4 qx, float4 qy, float4 qz, float tmax_w, float& tl,
                                                float& tr, bool& hl, bool& hr) {
-  const float t0xl = __builtin_fmaf(qx.x, s.ix, -s.nx), t0xr = __builtin_fmaf(qx.y, s.ix, -s.nx);
-  const float t1xl = __builtin_fmaf(qx.z, s.ixw, -s.fx), t1xr = __builtin_fmaf(qx.w, s.ixw, -s.fx);
-  const float t0yl = __builtin_fmaf(qy.x, s.iy, -s.ny), t0yr = __builtin_fmaf(qy.y, s.iy, -s.ny);
-  const float t1yl = __builtin_fmaf(qy.z, s.iyw, -s.fy), t1yr = __builtin_fmaf(qy.w, s.iyw, -s.fy);
-  const float t0zl = __builtin_fmaf(qz.x, s.iz, -s.nz), t0zr = __builtin_fmaf(qz.y, s.iz, -s.nz);
-  const float t1zl = __builtin_fmaf(qz.z, s.izw, -s.fz), t1zr = __builtin_fmaf(qz.w, s.izw, -s.fz);
-  tl = fmaxf(fmaxf(fmaxf(t0xl, t0yl), t0zl), 0.f);
-  tr = fmaxf(fmaxf(fmaxf(t0xr, t0yr), t0zr), 0.f);
-  const float fl = fminf(fminf(fminf(t1xl, t1yl), t1zl), tmax_w);
-  const float fr = fminf(fminf(fminf(t1xr, t1yr), t1zr), tmax_w);
+  // twelve plane distances in six packed FMAs (same IEEE fma per component as the scalar form: results are identical)
+  const f32x2 t0x = pk_planes_entry(f32x2{qx.x, qx.y}, s.mx, s.ax), t1x = pk_planes_exit(f32x2{qx.z, qx.w}, s.mx, s.ax);
+  const f32x2 t0y = pk_planes_entry(f32x2{qy.x, qy.y}, s.my, s.ay), t1y = pk_planes_exit(f32x2{qy.z, qy.w}, s.my, s.ay);
+  const f32x2 t0z = pk_planes_entry(f32x2{qz.x, qz.y}, s.mz, s.az), t1z = pk_planes_exit(f32x2{qz.z, qz.w}, s.mz, s.az);
+  tl = slab_max3_zero(slab_max(t0x.x, t0y.x), t0z.x);
+  tr = slab_max3_zero(slab_max(t0x.y, t0y.y), t0z.y);
+  const float fl = slab_min3(slab_min(t1x.x, t1y.x), t1z.x, tmax_w);
+  const float fr = slab_min3(slab_min(t1x.y, t1y.y), t1z.y, tmax_w);
   hl = tl <= fl;
   hr = tr <= fr;
 }
@@ -529,9 +551,13 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
 // at a time, so a wave can interleave lanes that are at different stages (k_fused's scheduler) or simply run it
 // to completion (traverse()).
 #define RT_DONE RT_EMPTY_CHILD
+// The "finished" marker of a traversal must survive a round trip through the stack (it sits at the bottom as a
+// sentinel): with 16-bit stack entries it is -32768 (leaf references ~prim stay above it: prim < 32 000), with 32-bit
+// entries RT_DONE itself.
+template <class StackT> struct TravDone { static constexpr int32_t v = sizeof(StackT) == 2 ? -32768 : RT_DONE; };
 struct TravState {
-  int32_t cur;  // >= 0 inner node, < 0 leaf (~prim), RT_DONE finished
-  int32_t sp;   // entries on the stack, INCLUDING the one cached in `top`
+  int32_t cur;  // >= 0 inner node, < 0 leaf (~prim), TravDone<StackT>::v finished
+  int32_t sp;   // entries of the stack held in LDS (the one above them is cached in `top`)
   int32_t top;  // top-of-stack kept in a register: a pop never waits on LDS (its refill load overlaps the next step)
   int32_t best_prim;
   float tmax_w;  // f32 upper bound of best_t, widened: ru(best_t) * RT_SLAB_WIDEN + 1e-30
@@ -546,33 +572,36 @@ __device__ __forceinline__ void trav_ray_constants(TravState& ts, d3 o, d3 d) {
   ts.s = make_slab(o, d);
 }
 // the part that records progress: current node, stack, best hit so far
-__device__ __forceinline__ void trav_restart(TravState& ts, int32_t root) {
+__device__ __forceinline__ void trav_restart(TravState& ts, int32_t root, int32_t done) {
   ts.cur = root;
   ts.sp = 0;
-  ts.top = RT_DONE;
+  ts.top = done;
   ts.best_prim = -1;
   ts.best_t = __builtin_inf();
   ts.tmax_w = __builtin_inff();
 }
-__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, d3 o, d3 d) {
-  trav_restart(ts, root);
+__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, int32_t done, d3 o, d3 d) {
+  trav_restart(ts, root, done);
   trav_ray_constants(ts, o, d);
 }
-// Stack with its top entry cached in a register.  `sp` counts the entries including the cached one; LDS slot k
-// holds entry k for k < sp - 1.  Both operations are branch-free: a push with an empty stack stores the (dead)
-// cached value into slot 0, a pop with fewer than two entries reads slot 0 and discards it.
+// Stack with its top entry cached in a register and a sentinel at the bottom.  `sp` counts the entries held in LDS
+// (row k of the lane's column = entry k); the register `top` is the entry above them.  A fresh traversal starts with
+// sp = 0 and top = the "finished" marker, so the first push parks that marker in row 0 and the pop that empties the
+// stack brings it back as the current node: no emptiness test anywhere.  A pop with sp = 0 (the traversal's last) reads
+// the row BELOW the column's first — the kernels keep readable LDS there (k_fused: the tile accumulators; the probe
+// kernels: a guard row) — and leaves a dead `top` that the next restart overwrites.
+// Push: one LDS store + one add; pop: one add + one LDS load (was 5 / 8 VALU instructions with clamps and a select).
 template <class StackT>
 __device__ __forceinline__ void trav_push(TravState& ts, int32_t v, StackT* stack, int stride) {
-  stack[max(ts.sp - 1, 0) * stride] = (StackT)ts.top;
+  stack[ts.sp * stride] = (StackT)ts.top;
   ts.top = v;
   ts.sp++;
 }
 template <class StackT>
 __device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int stride) {
-  ts.cur = ts.top;  // RT_DONE when the stack is empty
-  const int32_t below = (int32_t)stack[max(ts.sp - 2, 0) * stride];
-  ts.top = ts.sp >= 2 ? below : RT_DONE;
-  ts.sp = max(ts.sp - 1, 0);
+  ts.cur = ts.top;
+  ts.sp--;
+  ts.top = (int32_t)stack[ts.sp * stride];
 }
 // One step through a four-wide node: test the four boxes, continue with the nearest one hit and push the others
 // farthest first (5-exchange sorting network on (entry distance, link) pairs).  Unused slots carry an inverted
@@ -587,15 +616,20 @@ __device__ __forceinline__ void node_step_wide(const Acc& acc, TravState& ts, St
   const float INF = __builtin_inff();
   float t[4];
   int32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
-#define RT_WIDE_SLOT(k, m)                                                                                          \
+  // 24 plane distances in 12 packed FMAs: slots (0, 1) and (2, 3) pairwise
+  const f32x2 nx01 = pk_planes_entry(f32x2{ex.x, ex.y}, s.mx, s.ax), nx23 = pk_planes_entry(f32x2{ex.z, ex.w}, s.mx, s.ax);
+  const f32x2 ny01 = pk_planes_entry(f32x2{ey.x, ey.y}, s.my, s.ay), ny23 = pk_planes_entry(f32x2{ey.z, ey.w}, s.my, s.ay);
+  const f32x2 nz01 = pk_planes_entry(f32x2{ez.x, ez.y}, s.mz, s.az), nz23 = pk_planes_entry(f32x2{ez.z, ez.w}, s.mz, s.az);
+  const f32x2 fx01 = pk_planes_exit(f32x2{fx.x, fx.y}, s.mx, s.ax), fx23 = pk_planes_exit(f32x2{fx.z, fx.w}, s.mx, s.ax);
+  const f32x2 fy01 = pk_planes_exit(f32x2{fy.x, fy.y}, s.my, s.ay), fy23 = pk_planes_exit(f32x2{fy.z, fy.w}, s.my, s.ay);
+  const f32x2 fz01 = pk_planes_exit(f32x2{fz.x, fz.y}, s.mz, s.az), fz23 = pk_planes_exit(f32x2{fz.z, fz.w}, s.mz, s.az);
+#define RT_WIDE_SLOT(k, P, c)                                                                                       \
   {                                                                                                                 \
-    const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(ex.m, s.ix, -s.nx), __builtin_fmaf(ey.m, s.iy, -s.ny)),       \
-                                 __builtin_fmaf(ez.m, s.iz, -s.nz)), 0.f);                                          \
-    const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, s.ixw, -s.fx), __builtin_fmaf(fy.m, s.iyw, -s.fy)),     \
-                                 __builtin_fmaf(fz.m, s.izw, -s.fz)), ts.tmax_w);                                   \
+    const float tn = slab_max3_zero(slab_max(nx##P.c, ny##P.c), nz##P.c);                                           \
+    const float tf = slab_min3(slab_min(fx##P.c, fy##P.c), fz##P.c, ts.tmax_w);                                     \
     t[k] = tn <= tf ? tn : INF;                                                                                     \
   }
-  RT_WIDE_SLOT(0, x) RT_WIDE_SLOT(1, y) RT_WIDE_SLOT(2, z) RT_WIDE_SLOT(3, w)
+  RT_WIDE_SLOT(0, 01, x) RT_WIDE_SLOT(1, 01, y) RT_WIDE_SLOT(2, 23, x) RT_WIDE_SLOT(3, 23, y)
 #undef RT_WIDE_SLOT
 #define RT_WIDE_CAS(i, j)                                  \
   {                                                        \
@@ -632,7 +666,7 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
     else trav_pop(ts, stack, stride);
   }
 }
-// precondition: ts.cur < 0 && ts.cur != RT_DONE
+// precondition: ts.cur < 0 && ts.cur != TravDone<StackT>::v
 template <class Acc, class StackT>
 __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_t features, d3 o, d3 d, double time,
                                           double tmin, StackT* stack, int stride, PathRng& rng) {
@@ -682,9 +716,10 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
 template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
                                             double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng) {
+  constexpr int32_t kDone = TravDone<StackT>::v;
   TravState ts;
-  trav_init(ts, root, o, d);
-  while (ts.cur != RT_DONE) {
+  trav_init(ts, root, kDone, o, d);
+  while (ts.cur != kDone) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();
     while (ts.cur >= 0) {
@@ -692,7 +727,7 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
       node_step(acc, ts, stack, stride);
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
-    if (ts.cur != RT_DONE) {
+    if (ts.cur != kDone) {
       if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
       leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
@@ -713,9 +748,10 @@ template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, bool participating, uint32_t features,
                                                 d3 o, d3 d, double time, double tmin, StackT* stack, int stride,
                                                 TravCounters* cnt, PathRng& rng, uint32_t min_busy, uint32_t kn) {
-  if (!participating) ts.cur = RT_DONE;  // lanes without a path: nothing to walk (keeps the loop predicates to one compare)
+  constexpr int32_t kDone = TravDone<StackT>::v;
+  if (!participating) ts.cur = kDone;  // lanes without a path: nothing to walk (keeps the loop predicates to one compare)
   while (true) {
-    const unsigned long long m_busy = wave_ballot(ts.cur != RT_DONE);
+    const unsigned long long m_busy = wave_ballot(ts.cur != kDone);
     if ((uint32_t)__popcll(m_busy) < min_busy) break;
     bool at_node = ts.cur >= 0;
     unsigned long long m_node = wave_ballot(at_node);
@@ -731,7 +767,7 @@ __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, b
       m_node = wave_ballot(at_node);
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
-    if (ts.cur < 0 && ts.cur != RT_DONE) {
+    if (ts.cur < 0 && ts.cur != kDone) {
       if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
       leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Camera cam, Queue q, floa
 template <bool SPHERES>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(Scene sc, uint32_t features, Queue q, Hits h,
                                                         const uint32_t* __restrict__ count) {
-  __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+  __shared__ uint32_t stack_rows[(RT_STACK_DEPTH + 1) * RT_BLOCK];  // row 0: guard row below the columns (trav_pop)
+  uint32_t* const stack = stack_rows + RT_BLOCK;
   const uint32_t n = *count;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -399,7 +400,8 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   // RESUME: the lane's traversal progress (node, stack, best hit) survives shade / regenerate rounds of its
   // neighbours; the per-ray constants are recomputed each round (unconditionally, so that they are not live across
   // the shading code)
-  int32_t t_cur = RT_DONE, t_sp = 0, t_top = RT_DONE, t_best_prim = -1;
+  constexpr int32_t kDone = TravDone<StackT>::v;
+  int32_t t_cur = kDone, t_sp = 0, t_top = kDone, t_best_prim = -1;
   double t_best_t = 0;
   bool fresh_lane = false;  // this lane holds a ray whose traversal has not started
   bool fresh = false;       // wave-uniform: some lane received a new ray since the last traversal call
@@ -592,7 +594,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     if (RESUME) {
       TravState ts;
       trav_ray_constants(ts, o, d);  // all lanes (garbage in lanes without a path is never used)
-      if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = 0; t_top = RT_DONE; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
+      if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = 0; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
       fresh_lane = false;
       ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
       ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
@@ -601,7 +603,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
                                                                  &tc, rng, fresh ? fp.kb : 1u, fp.kn);
       t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
-      const bool ready = active && t_cur == RT_DONE;
+      const bool ready = active && t_cur == kDone;
       fresh = __ballot(ready) != 0ull;
       int32_t flush_slot = -1;  // this lane finished the last path of that slot's tile
       if (ready) {
@@ -706,7 +708,8 @@ template <int TREE>
 __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features, const rt_ray* __restrict__ rays,
                                                     uint32_t n, rt_hit* __restrict__ out,
                                                     unsigned long long* __restrict__ trav_counters) {
-  __shared__ uint32_t stack[RT_STACK_DEPTH * RT_BLOCK];
+  __shared__ uint32_t stack_rows[(RT_STACK_DEPTH + 1) * RT_BLOCK];  // row 0: guard row below the columns (trav_pop)
+  uint32_t* const stack = stack_rows + RT_BLOCK;
   const uint32_t stride = gridDim.x * blockDim.x;
   TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
