@@ -11,8 +11,10 @@
  * rt_status (0 = OK, <0 = error) unless stated otherwise and never unwinds, throws or aborts across the
  * boundary.  `rt_last_error(ctx)` returns a UTF-8 message owned by the ctx.  A ctx is bound to ONE GPU and
  * is NOT thread-safe (one ctx per calling thread; the reference calls render from one dedicated thread,
- * src/main.rs:50-58).  Multi-GPU = one process (or thread) + one ctx per GPU, each rendering a disjoint
- * residue class of the per-pixel sample indices; the caller sums the partial frames (RCCL reduce).
+ * src/main.rs:50-58).  Multi-GPU: either the rt_multi_* entry points below (one call, library-owned contexts and
+ * host threads, frames summed over xGMI inside the library), or one process + one ctx per GPU, each rendering a
+ * disjoint residue class of the per-pixel sample indices with the caller summing the partial frames (RCCL reduce:
+ * what bench.py does).
  */
 #ifndef RT_ABI_H
 #define RT_ABI_H
@@ -246,6 +248,38 @@ uint32_t rt_half_round_bits(float x, int up);
 
 /* Synchronise the ctx's stream (for callers of the *_device entry points). */
 int rt_synchronize(rt_ctx* ctx);
+
+/* ---- several GPUs of one node behind one call -----------------------------------------------------------
+ * Replaces: the same blocking seam, Camera::render (src/camera/mod.rs:54-58) reached through Scene::render
+ * (src/scene.rs:30-32), for a caller with N GPUs (no counterpart in the reference, which is one process on CPU
+ * threads; its pixel is a plain sum over independent samples, mod.rs:151-172, which is what makes the split exact).
+ * An rt_multi owns one rt_ctx and one persistent host thread per listed device.  rt_multi_render renders, on device i
+ * of n, the sample indices {sample_begin + (i + k n) * sample_stride < sample_end} of every pixel, then sums the n
+ * partial f32 frames on the FIRST device of the list with one kernel that reads the other devices' frames in place
+ * over xGMI (peer access; seven dedicated links feed the root concurrently), and returns the un-normalised sums like
+ * rt_render.  The result equals the single-device frame up to f32 summation order.  A device may be listed more than
+ * once (several contexts on one GPU: how the one-GPU tests drive this path).  Not thread-safe: one caller at a time. */
+typedef struct rt_multi rt_multi;
+typedef struct rt_multi_stats {
+  uint32_t n_devices, reserved;
+  uint64_t paths, rays;          /* over all devices, last render */
+  float ms_render[16];           /* hipEvent time of each device's render */
+  float ms_reduce, ms_copy;      /* the summing kernel on the root device / the copy of the result to the caller */
+} rt_multi_stats;
+int rt_multi_init(const int* device_ids, int n_devices, rt_multi** out); /* 1..16 devices; the first is the root */
+int rt_multi_shutdown(rt_multi* m);
+const char* rt_multi_last_error(rt_multi* m); /* NULL: message of the last failing rt_multi_init */
+int rt_multi_device_count(rt_multi* m);
+/* rt_scene_upload on every device (replaces the previous scene); the caller keeps ownership of `desc`. */
+int rt_multi_scene_upload(rt_multi* m, const rt_scene_desc* desc);
+/* HOST output pointer (W*H*3 f32), blocking. */
+int rt_multi_render(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t sample_begin, uint32_t sample_end,
+                    uint32_t sample_stride, float* out_sum);
+/* Output pointer in the ROOT device's memory, blocking (the sum stays on the GPU: for rt_resolve_device on it). */
+int rt_multi_render_device(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t sample_begin, uint32_t sample_end,
+                           uint32_t sample_stride, float* d_out_sum_root);
+int rt_multi_set_option(rt_multi* m, const char* key, int64_t value); /* rt_set_option on every device */
+int rt_multi_get_stats(rt_multi* m, rt_multi_stats* out);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,8 @@ ABI_SYMBOLS = [
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free", "rt_intersect",
     "rt_render", "rt_render_device", "rt_resolve", "rt_resolve_device", "rt_get_stats", "rt_set_option",
     "rt_philox4x32_10", "rt_half_round_bits", "rt_synchronize", "rt_render_device_noalloc",
+    "rt_multi_init", "rt_multi_shutdown", "rt_multi_last_error", "rt_multi_device_count", "rt_multi_scene_upload",
+    "rt_multi_render", "rt_multi_render_device", "rt_multi_set_option", "rt_multi_get_stats",
 ]
 
 
@@ -71,6 +73,11 @@ class RtStats(C.Structure):
                 ("dbg", C.c_float * 16)]
 
 
+class RtMultiStats(C.Structure):
+    _fields_ = [("n_devices", C.c_uint32), ("reserved", C.c_uint32), ("paths", C.c_uint64), ("rays", C.c_uint64),
+                ("ms_render", C.c_float * 16), ("ms_reduce", C.c_float), ("ms_copy", C.c_float)]
+
+
 RAY_DTYPE = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("time", "<f8")])
 HIT_DTYPE = np.dtype([("object_id", "<i4"), ("front_face", "<i4"), ("t", "<f8"), ("p", "<f8", 3), ("n", "<f8", 3),
                       ("u", "<f8"), ("v", "<f8")])
@@ -109,6 +116,16 @@ def lib():
     L.rt_half_round_bits.argtypes = [C.c_float, C.c_int]
     L.rt_half_round_bits.restype = C.c_uint32
     L.rt_synchronize.argtypes = [vp]
+    L.rt_multi_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.rt_multi_shutdown.argtypes = [vp]
+    L.rt_multi_last_error.argtypes = [vp]
+    L.rt_multi_last_error.restype = C.c_char_p
+    L.rt_multi_device_count.argtypes = [vp]
+    L.rt_multi_scene_upload.argtypes = [vp, C.POINTER(RtSceneDesc)]
+    L.rt_multi_render.argtypes = [vp, C.POINTER(RtCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.rt_multi_render_device.argtypes = L.rt_multi_render.argtypes
+    L.rt_multi_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.rt_multi_get_stats.argtypes = [vp, C.POINTER(RtMultiStats)]
     _gpu = L
     return L
 
@@ -244,6 +261,62 @@ class DeviceScene:
         fn = self.ctx.L.rt_render_device_noalloc if no_alloc else self.ctx.L.rt_render_device
         self.ctx.check(fn(self.ctx.h, self.h, C.byref(cam), seed, sample_begin, sample_end, sample_stride, d_out_ptr,
                           stream))
+
+
+class MultiContext:
+    """Several GPUs of one node behind one render call (rt_multi): one context + host thread per listed device, sample
+    indices split by residue class, partial frames summed on the first device over xGMI."""
+
+    def __init__(self, device_ids):
+        self.L = lib()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self.L.rt_multi_init(ids, len(device_ids), C.byref(h))
+        if rc != RT_OK:
+            raise RtError(rc, self.L.rt_multi_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_multi_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self.L.rt_multi_last_error(self.h).decode())
+
+    def device_count(self):
+        return self.L.rt_multi_device_count(self.h)
+
+    def set_option(self, key, value):
+        self.check(self.L.rt_multi_set_option(self.h, key.encode(), int(value)))
+
+    def upload(self, desc):
+        self.check(self.L.rt_multi_scene_upload(self.h, desc))
+
+    def render_sums(self, cam, seed=0, sample_begin=0, sample_end=None, sample_stride=1):
+        if sample_end is None:
+            sample_end = cam.sampler_n * cam.sampler_n if cam.sampler_kind == 0 else cam.sampler_n
+        out = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+        self.check(self.L.rt_multi_render(self.h, C.byref(cam), seed, sample_begin, sample_end, sample_stride,
+                                          out.ctypes.data))
+        return out
+
+    def render_device(self, cam, d_out_ptr, seed=0, sample_begin=0, sample_end=None, sample_stride=1):
+        if sample_end is None:
+            sample_end = cam.sampler_n * cam.sampler_n if cam.sampler_kind == 0 else cam.sampler_n
+        self.check(self.L.rt_multi_render_device(self.h, C.byref(cam), seed, sample_begin, sample_end, sample_stride,
+                                                 d_out_ptr))
+
+    def stats(self):
+        s = RtMultiStats()
+        self.check(self.L.rt_multi_get_stats(self.h, C.byref(s)))
+        n = s.n_devices
+        return {"n_devices": n, "paths": s.paths, "rays": s.rays, "ms_render": list(s.ms_render)[:n],
+                "ms_reduce": s.ms_reduce, "ms_copy": s.ms_copy}
 
 
 def resolve(ctx, sums, spp, gamma=2.2, want_u8=False):

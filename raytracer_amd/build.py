@@ -33,7 +33,8 @@ def build(force=False, verbose=False):
     abi = os.path.join(os.path.dirname(HERE), "include", "rt_abi.h")
     if force or _newer(LIB_GPU, _sources(CSRC) + [abi]):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", "-o", LIB_GPU, os.path.join(CSRC, "rt_lib.hip"), os.path.join(CSRC, "rt_bvh.cpp")]
+               "-Wno-unused-function", "-o", LIB_GPU, os.path.join(CSRC, "rt_lib.hip"), os.path.join(CSRC, "rt_multi.hip"),
+               os.path.join(CSRC, "rt_bvh.cpp"), "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

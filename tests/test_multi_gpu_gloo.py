@@ -63,6 +63,26 @@ def test_sample_partition_covers_every_sample_once():
         assert sorted(seen) == list(range(SPP))
 
 
+def test_nested_partition_composes():
+    """A node-level split (rt_multi_render: begin, stride given by an outer split across nodes) inside an outer split:
+    every sample index is still rendered exactly once."""
+    for outer in (1, 2, 3):
+        for inner in (1, 2, 4, 8):
+            seen = []
+            for o in range(outer):
+                ob, oe, ost = mg.sample_slice(o, outer, SPP)
+                for i in range(inner):
+                    b, e, st = mg.sample_slice(i, inner, oe, begin=ob, stride=ost)
+                    seen += list(range(b, e, st))
+            assert sorted(seen) == list(range(SPP)), (outer, inner)
+    # more ranks than samples: the surplus ranks get empty ranges, nothing is rendered twice
+    seen = []
+    for r in range(8):
+        b, e, st = mg.sample_slice(r, 8, 5)
+        seen += list(range(b, e, st))
+    assert sorted(seen) == list(range(5))
+
+
 def test_two_rank_gloo_reduce_equals_single_process(tmp_path):
     out = str(tmp_path / "sum.npy")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
