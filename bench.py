@@ -5,22 +5,27 @@ configs[1] (book_cover: bouncing spheres + motion blur + checker ground, 1200x67
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full render of the frame on every rank: each rank renders ALL of the config's per-pixel sample
-indices (100 spp) for the whole frame with its own Philox key (decorrelated streams per GPU), the partial f32
-frames are summed on rank 0 with one RCCL reduce, and rank 0 resolves (mean over N x 100 samples, gamma 2.2,
+A "step" is one render of THE CONFIG'S FRAME — 1200 x 675 pixels x 100 samples = 81 M samples — by all ranks
+together: rank r of N renders the residue class r (mod N) of the 100 per-pixel sample indices for the whole frame
+(north_star: "splitting samples-per-pixel into decorrelated RNG streams per GPU"; a path is a function of its sample
+index, so the N-rank frame IS the one-rank frame up to f32 summation order — asserted on rank 0 after the timed
+region), the partial f32 frames are summed on rank 0 with one RCCL reduce, and rank 0 resolves (mean, gamma 2.2,
 8-bit).  Scene and camera are resident in HBM before the timed region; outputs stay on the device.
 
-Scaling is therefore WEAK (per-GPU work fixed: `spp_per_gpu` = 100; at N GPUs the frame converges with N x 100
-spp); value = samples of all ranks / max-over-ranks time.  (A fixed sample budget is split by residue class of the
-sample index instead — `rt_render(..., sample_begin = rank, sample_stride = N)`, raytracer_amd/multi_gpu.py.)
+Scaling is therefore STRONG (total work fixed; at 8 GPUs each renders 12-13 spp, ~1.2 ms of kernel).  value = 81 M x
+steps / max-over-ranks time.  Secondary fields: `reduce_ms` (the RCCL reduce alone), `weak` (every rank renders all
+100 spp with its own key: per-GPU work fixed).
 
 The JSON line also carries
-  roofline      FP32-VALU roofline of the render kernels (algorithmic flops/sample from the
-                instrumented oracle on the reference-topology BVH x samples per step / hipEvent kernel time)
+  roofline      FP32-VALU roofline of the render kernel (algorithmic flops/sample from the instrumented
+                oracle on the reference-topology BVH x samples per launch / hipEvent kernel time), the share of those
+                flops that run in f64, and — from the committed PMC profile of the same command — the EXECUTED figure
+                (VALU lane-operations per second against the lane peak)
   cpu_baseline  the CPU oracle (C++ restatement of the reference) timed on this host on a bounded sample
+  workloads     (N = 1) the north_star's target workload C5 (Next Week final scene, 4K) and C4 (Cornell smoke): the
+                same measurements + their own CPU legs and GPU / CPU ratios
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -30,25 +35,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 flop x 2.4 GHz
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 lanes x 2 (packed) x 2 flop x 2.4 GHz
+VALU_FP64_PEAK_TFLOPS = 78.6   # vector f64 FMA: one per lane and clock (the unpacked f32 rate)
+VALU_LANE_PEAK_TOPS = 39.3     # lane-operations per second: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
 
 WORKLOADS = {
-    # name: (scene, width, sampler, spp rendered per step, depth, workload fixture)
-    "c1": ("book_cover", 400, "random", 10, 50, "workload_c1.json"),
-    "c2": ("book_cover", 1200, "uniform", 100, 50, "workload_c2.json"),
-    "c3a": ("earth", 1920, "uniform", 256, 50, "workload_c3a.json"),
-    "c3b": ("something_blocky", 1920, "uniform", 256, 50, "workload_c3b.json"),
-    "c4": ("cornell_smoke", 1920, "uniform", 64, 50, "workload_c4.json"),    # config: 1024 spp; step = 64 spp slice
-    "c5": ("final_scene", 3840, "uniform", 16, 50, "workload_c5.json"),      # config: 10 000 spp; step = 16 spp slice
+    # name: (scene, width, sampler, spp rendered per step, depth, workload fixture, config spp)
+    "c1": ("book_cover", 400, "random", 10, 50, "workload_c1.json", 10),
+    "c2": ("book_cover", 1200, "uniform", 100, 50, "workload_c2.json", 100),
+    "c3a": ("earth", 1920, "uniform", 256, 50, "workload_c3a.json", 256),
+    "c3b": ("something_blocky", 1920, "uniform", 256, 50, "workload_c3b.json", 256),
+    "c4": ("cornell_smoke", 1920, "uniform", 64, 50, "workload_c4.json", 1024),    # step = 64-spp slice
+    "c5": ("final_scene", 3840, "uniform", 16, 50, "workload_c5.json", 10000),     # step = 16-spp slice
 }
+# integer work the flop count leaves out (reported separately): the noise texture's lattice hash
+NOISE_INT_OPS_REFERENCE = 8 * (128 * 8 + 64)   # texture.rs:148-162 as written: 8 corners x (128 xoroshiro steps + jump XORs)
+NOISE_INT_OPS_GPU = 40 * 6 + 8 * 12            # 40 GF(2) table lookups (load + 4 xor each) + 8 x (add, convert)
 
 
-def cpu_baseline(scene, width, depth, texels=None):
+def cpu_baseline(scene, width, depth, texels=None, cspp=None):
     """Oracle (kind 'port') on a bounded sample of the same workload (about 10-20 s of wall time on 16 threads):
     the same frame at the config's own 100 spp for C2 (width 1200), 16 spp for the 1920-wide frames, 1 spp at 4K."""
     from oracle_lib import OracleScene
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share is 16
-    cspp = 100 if width <= 1200 else (16 if width <= 1920 else 1)
+    if cspp is None:
+        cspp = 100 if width <= 1200 else (16 if width <= 1920 else 1)
     sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", cspp, depth, texels=texels)
     r = sc.render(threads=threads)
     n = sc.width * sc.height * cspp
@@ -65,6 +76,89 @@ def cpu_baseline(scene, width, depth, texels=None):
     }
 
 
+def f64_share(wl):
+    """Share of the algorithmic flops that this implementation executes in f64: the camera ray, the sphere
+    / quad / medium tests, the hit point, checker / noise lattice coordinates.  Boxes, scatter, sky, throughput: f32."""
+    p, F = wl["per_sample"], wl["flop_constants"]
+    f64 = (F["cam"] + F["sph"] * p["sphere_tests"] + F["sph_root"] * p["sphere_disc_pos"] + F["mov"] * p["moving_tests"] +
+           F["quad"] * p["quad_tests"] + F["medium"] * p["medium_tests"] + 6 * p["bounce_hits"] +
+           F["tex_chk"] * p["tex_checker"] + F["tex_noise"] * p["tex_noise"])
+    return f64 / wl["flops_per_sample"]
+
+
+def load_pmc(workload):
+    """Committed rocprofv3 PMC summary of `bench.py --workload <w>` (scripts/gpu_profile.sh + summarize_profile.py)."""
+    for name in (f"pmc_{workload}_latest.json", "pmc_latest.json" if workload == "c2" else None):
+        if name and os.path.exists(os.path.join(ROOT, "profiles", name)):
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f), "profiles/" + name
+    return None, None
+
+
+def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats):
+    fps = wl["flops_per_sample"]
+    achieved = samples_per_launch * fps / (kernel_ms * 1e-3) / 1e12
+    share = f64_share(wl)
+    # a kernel whose flops are `share` f64 and the rest packed f32 cannot beat this mixed peak
+    mixed_peak = 1.0 / ((1.0 - share) / VALU_FP32_PEAK_TFLOPS + share / VALU_FP64_PEAK_TFLOPS)
+    out = {"bound": "valu_fp32", "achieved": achieved, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": achieved / VALU_FP32_PEAK_TFLOPS, "traffic": None,
+           "kernel": "k_fused (persistent fused path-tracing kernel), per rt_render_device call",
+           "kernel_ms_per_step": kernel_ms, "algorithmic_flops_per_sample": fps,
+           "f64_share_of_algorithmic_flops": share, "mixed_f32_f64_peak": mixed_peak, "frac_of_mixed_peak": achieved / mixed_peak,
+           "rays_per_sample": stats["rays"] / max(stats["paths"], 1)}
+    if wl["per_sample"].get("tex_noise", 0) > 0:
+        out["integer_ops_per_sample_not_in_flops"] = {
+            "noise_lookups_per_sample": wl["per_sample"]["tex_noise"],
+            "reference_int_ops_per_lookup": NOISE_INT_OPS_REFERENCE, "gpu_int_ops_per_lookup": NOISE_INT_OPS_GPU,
+            "reference_int_ops_per_sample": wl["per_sample"]["tex_noise"] * NOISE_INT_OPS_REFERENCE,
+            "gpu_int_ops_per_sample": wl["per_sample"]["tex_noise"] * NOISE_INT_OPS_GPU}
+    pmc, src = load_pmc(workload)
+    if pmc:
+        der, cnt = pmc.get("derived", {}), pmc.get("counters", {})
+        if "hbm_write_bytes" in der and "hbm_fetch_bytes_x2_upper" in der:
+            out["traffic"] = der["hbm_fetch_bytes_x2_upper"] + der["hbm_write_bytes"]
+            out["traffic_note"] = ("HBM bytes per launch (rocprofv3 FETCH_SIZE x2 upper bound + WRITE_SIZE, " + src +
+                                   "); algorithmic output is W*H*12 B; scene and path state live in LDS / L2 / registers")
+        if "SQ_INSTS_VALU" in cnt and der.get("valu_active_lane_fraction"):
+            lane_ops = cnt["SQ_INSTS_VALU"] * 64 * der["valu_active_lane_fraction"]
+            out["executed"] = {
+                "valu_wave_instructions_per_launch": cnt["SQ_INSTS_VALU"],
+                "valu_active_lane_fraction": der["valu_active_lane_fraction"],
+                "lane_ops_per_s_tera": lane_ops / (kernel_ms * 1e-3) / 1e12, "lane_peak_tera": VALU_LANE_PEAK_TOPS,
+                "lane_utilisation": lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_LANE_PEAK_TOPS,
+                "l2_hit_rate": der.get("l2_hit_rate"),
+                "note": "committed profile of the same command (" + src + "), collected with kernels serialised; "
+                        "lane_utilisation = VALU lane-operations actually executed per second / (256 CU x 64 lanes x "
+                        "2.4 GHz): what the hardware did, as opposed to `frac`, which prices the REFERENCE algorithm's "
+                        "flops (on the reference's tree) at this kernel's speed"}
+    return out
+
+
+class Rig:
+    """One workload resident on this rank's GPU."""
+
+    def __init__(self, ra, ctx, workload):
+        self.name = workload
+        scene_name, width, sampler, spp, depth, fixture, config_spp = WORKLOADS[workload]
+        self.scene_name, self.width_req, self.sampler, self.depth, self.config_spp = scene_name, width, sampler, depth, config_spp
+        self.texels = None
+        if scene_name in ("earth", "final_scene"):
+            from golden_data import load_earth_rgba
+            self.texels = load_earth_rgba()
+        self.host = ra.Scene(scene_name, width, 16.0 / 9.0, sampler, spp, depth, texels=self.texels)
+        self.dev = self.host.upload(ctx)
+        self.cam = self.host.camera_copy()
+        self.W, self.H, self.spp = self.host.width, self.host.height, self.host.spp
+        with open(os.path.join(ROOT, "tests", "golden", fixture)) as f:
+            self.wl = json.load(f)
+
+    def label(self):
+        return (f"{self.name}: {self.scene_name} {self.W}x{self.H}, {self.sampler}_sampler({self.spp}), depth {self.depth}, "
+                f"{self.host.desc.n_prims} primitives" + (f" ({self.spp}-spp slice of the config's {self.config_spp})"
+                                                           if self.spp != self.config_spp else ""))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +166,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-stages", action="store_true", help="extra untimed step with per-stage hipEvents")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the C5 / C4 block of the N = 1 line")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="rt_set_option override (profiling runs: fused_partner=0, rocprofv3 serialises kernels)")
     ap.add_argument("--rehearse", action="store_true",
                     help="rehearsal of the N>1 code path on a one-GPU box: every rank renders on GPU 0 and the "
                          "partial frames are reduced with gloo through host memory (not a measurement)")
@@ -99,130 +195,159 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    import numpy as np
     import raytracer_amd as ra
-    scene_name, width, sampler, spp, depth, fixture = WORKLOADS[args.workload]
+    from raytracer_amd import multi_gpu as mg
     ctx = ra.Context(local_rank)
-    # weak scaling: every rank renders `spp` samples per pixel; the frame holds world*spp samples.
-    # Uniform sampler needs a square count: use the grid of the config per rank by offsetting the seed per rank
-    # (decorrelated Philox streams per GPU) and letting each rank render the config's full grid.
-    texels = None
-    if scene_name in ("earth", "final_scene"):
-        from golden_data import load_earth_rgba
-        texels = load_earth_rgba()
-    host_scene = ra.Scene(scene_name, width, 16.0 / 9.0, sampler, spp, depth, texels=texels)
-    dev_scene = host_scene.upload(ctx)
-    cam = host_scene.camera_copy()
-    W, H = host_scene.width, host_scene.height
-    samples_per_rank = W * H * host_scene.spp
+    for kv in args.option:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    rig = Rig(ra, ctx, args.workload)
+    W, H = rig.W, rig.H
+    frame_samples = W * H * rig.spp
+    seed0 = 0x853C49E6748FEA9B
+    # Everything runs on a stream of torch's own: its handle is non-zero, so the library launches ON it (a NULL stream
+    # means "the context's own stream" in the ABI) and the RCCL reduce, which torch orders against the current stream,
+    # sees finished frames without any host wait.
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
     d_sum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     d_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-    seed0 = 0x853C49E6748FEA9B
 
-    def step(i):
-        # rank r draws from its own Philox key => decorrelated streams per GPU (north_star)
-        seed = (seed0 + 0x9E3779B97F4A7C15 * (rank + 1) + i) & 0xFFFFFFFFFFFFFFFF
-        dev_scene.render_device(cam, d_sum.data_ptr(), seed=seed, stream=stream)
+    def reduce_to_rank0():
         if world > 1 and args.rehearse:
             h = d_sum.cpu()
             dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
             d_sum.copy_(h)
         elif world > 1:
             dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+
+    def resolve(spp_total):
         if rank == 0:
-            ctx.check(ctx.L.rt_resolve_device(ctx.h, d_sum.data_ptr(), W, H, host_scene.spp * world, 2.2, None,
-                                              d_u8.data_ptr(), stream))
+            ctx.check(ctx.L.rt_resolve_device(ctx.h, d_sum.data_ptr(), W, H, spp_total, 2.2, None, d_u8.data_ptr(), stream))
+
+    def step_strong(i):
+        # the config's frame, split: rank r renders sample indices r, r + N, ... of every pixel (same key on all ranks)
+        b, e, s = mg.sample_slice(rank, world, rig.spp)
+        rig.dev.render_device(rig.cam, d_sum.data_ptr(), seed=(seed0 + i) & 0xFFFFFFFFFFFFFFFF, sample_begin=b, sample_end=e,
+                              sample_stride=s, stream=stream)
+        reduce_to_rank0()
+        resolve(rig.spp)
+
+    def step_weak(i):
+        # every rank renders ALL the config's sample indices with its own key: the frame converges with N x spp samples
+        seed = (seed0 + 0x9E3779B97F4A7C15 * (rank + 1) + i) & 0xFFFFFFFFFFFFFFFF
+        rig.dev.render_device(rig.cam, d_sum.data_ptr(), seed=seed, stream=stream)
+        reduce_to_rank0()
+        resolve(rig.spp * world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
+    def timed(step, n_steps, n_warm):
+        for i in range(n_warm):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(n_warm + i)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed(step_strong, args.steps, args.warmup)
+
+    # per-step hipEvent time of this rank's render kernel (events recorded by the library on the launch stream); measured
+    # on an extra replay after the timed region so that reading stats does not serialise the steps
     kernel_ms = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    # per-step hipEvent time of the render kernels (events recorded by the library on the launch stream);
-    # measured on an extra replay after the timed region so that reading stats does not serialise the steps
     for i in range(min(args.steps, 3)):
-        step(args.warmup + i)
+        step_strong(args.warmup + i)
         torch.cuda.synchronize()
         kernel_ms.append(ctx.stats()["ms_total"])
     stats = ctx.stats()
-    stage = None
-    if args.profile_stages:
-        ctx.set_option("profile", 1)
-        step(0)
-        torch.cuda.synchronize()
-        s = ctx.stats()
-        stage = {k: s[k] for k in ("ms_generate", "ms_intersect", "ms_shade", "ms_accumulate", "ms_total")}
-        ctx.set_option("profile", 0)
+    k_ms = sorted(kernel_ms)[len(kernel_ms) // 2]
+    my_samples = stats["paths"]
 
+    extra = {}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # (1) the N-rank frame is the one-rank frame: rank 0 renders the whole frame itself and compares
+        step_strong(12345)
+        torch.cuda.synchronize()
+        if rank == 0:
+            got = d_sum.cpu().numpy()
+            whole = torch.zeros_like(d_sum)
+            rig.dev.render_device(rig.cam, whole.data_ptr(), seed=(seed0 + 12345) & 0xFFFFFFFFFFFFFFFF, stream=stream)
+            torch.cuda.synchronize()
+            ref = whole.cpu().numpy()
+            err = float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)))
+            assert err <= 1e-5, f"the {world}-rank frame differs from the one-rank frame (max rel. error {err:.3g})"
+            extra["split_frame_max_rel_error_vs_one_rank"] = err
+        # (2) the reduce alone (all ranks enter together)
+        barrier()
+        t0 = time.perf_counter()
+        R = 10
+        for _ in range(R):
+            reduce_to_rank0()
+        barrier()
+        extra["reduce_ms"] = (time.perf_counter() - t0) / R * 1e3
+        extra["reduce_bytes_per_rank"] = W * H * 12
+        # (3) weak scaling, secondary
+        wsteps = max(1, min(args.steps, 5))
+        wel = timed(step_weak, wsteps, 1)
+        extra["weak"] = {"value": frame_samples * world * wsteps / wel / 1e6, "unit": "Msamples/s",
+                         "ms_per_step": wel / wsteps * 1e3, "steps": wsteps, "spp_per_gpu": rig.spp,
+                         "note": "every rank renders the config's full 100 spp with its own key (per-GPU work fixed)"}
 
     if rank == 0:
-        total_samples = samples_per_rank * world * args.steps
-        value = total_samples / elapsed / 1e6
-        with open(os.path.join(ROOT, "tests", "golden", fixture)) as f:
-            wl = json.load(f)
-        fps = wl["flops_per_sample"]
-        k_ms = sorted(kernel_ms)[len(kernel_ms) // 2]
-        achieved = samples_per_rank * fps / (k_ms * 1e-3) / 1e12
-        # HBM bytes per launch from the committed PMC profile of this workload (FETCH_SIZE / WRITE_SIZE passes of
-        # scripts/gpu_profile.sh, summarised by scripts/summarize_profile.py; c5: scripts/pmc_c5.sh)
-        traffic, pmc_extra = None, None
-        traffic_src = "profiles/pmc_latest.json"
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        c5_path = os.path.join(ROOT, "profiles", "r01_c5_v9_pmc.json")
-        if args.workload == "c5" and world == 1 and os.path.exists(c5_path):
-            with open(c5_path) as f:
-                der = json.load(f).get("derived", {})
-            if "hbm_write_bytes" in der and "hbm_fetch_bytes_raw" in der:
-                traffic = 2 * der["hbm_fetch_bytes_raw"] + der["hbm_write_bytes"]  # FETCH_SIZE x2: upper bound (guide)
-                traffic_src = "profiles/r01_c5_v9_pmc.json"
-        if args.workload == "c2" and world == 1 and os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            der, cnt = pmc.get("derived", {}), pmc.get("counters", {})
-            if "hbm_write_bytes" in der and "hbm_fetch_bytes_x2_upper" in der:
-                traffic = der["hbm_fetch_bytes_x2_upper"] + der["hbm_write_bytes"]
-            if "SQ_INSTS_VALU" in cnt:  # committed profile of the same command (not measured in this run)
-                pmc_extra = {"valu_wave_instructions_per_launch": cnt["SQ_INSTS_VALU"],
-                             "valu_active_lane_fraction": der.get("valu_active_lane_fraction"),
-                             "l2_hit_rate": der.get("l2_hit_rate"), "source": "profiles/pmc_latest.json"}
+        value = frame_samples * args.steps / elapsed / 1e6
         out = {
             "metric": "Msamples/sec (pixels x spp)", "value": value, "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + f32 culling/shading",
-            "data": f"synthetic (scene builder {scene_name}, fixed seeds)" + (" REHEARSAL, not a measurement" if args.rehearse else ""),
-            "config": {"workload": f"{args.workload}: {scene_name} {W}x{H}, {sampler}_sampler({host_scene.spp}), "
-                                   f"depth {depth}, {host_scene.desc.n_prims} primitives",
-                       "spp_per_gpu": host_scene.spp, "samples_per_step": samples_per_rank * world,
-                       "parallelism": f"sample-split x{world} + RCCL reduce" if world > 1 else "single GPU"},
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / VALU_FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 upper bound + WRITE_SIZE, "
-                                         + traffic_src + "); the kernel is compute-bound, scene and path "
-                                         "state live in LDS / L2 / registers",
-                         "kernel": "k_fused (persistent fused path-tracing kernel), per rt_render_device call",
-                         "kernel_ms_per_step": k_ms, "algorithmic_flops_per_sample": fps,
-                         "rays_per_sample": stats["rays"] / max(stats["paths"], 1)},
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 geometry + f32 culling/shading",
+            "data": f"synthetic (scene builder {rig.scene_name}, fixed seeds)" + (" REHEARSAL, not a measurement" if args.rehearse else ""),
+            "config": {"workload": rig.label(), "samples_per_step": frame_samples,
+                       "spp_per_gpu": [mg.samples_in_slice(*mg.sample_slice(r, world, rig.spp)) for r in range(world)],
+                       "parallelism": (f"sample indices split x{world} (residue classes) + one RCCL reduce of "
+                                       f"{W * H * 12} B per rank") if world > 1 else "single GPU"},
+            "roofline": roofline_block(args.workload, rig.wl, my_samples, k_ms, stats),
         }
-        if pmc_extra:
-            out["roofline"]["pmc"] = pmc_extra
-        if stage:
-            out["roofline"]["stage_ms"] = stage
+        out["roofline"]["note"] = ("rank 0's launch: %d of the frame's %d samples" % (my_samples, frame_samples)) if world > 1 else \
+            "one launch = the whole frame"
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would idle on it)
-            out["cpu_baseline"] = cpu_baseline(scene_name, width, depth, texels)
+            out["cpu_baseline"] = cpu_baseline(rig.scene_name, rig.width_req, rig.depth, rig.texels)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and args.workload == "c2" and not args.no_workloads:
+            # the north_star's target workload (C5) and the emissive / volume workload (C4), with their own CPU legs
+            out["workloads"] = {}
+            for w, csp in (("c5", 1), ("c4", 4)):
+                r2 = Rig(ra, ctx, w)
+                d2 = torch.zeros((r2.H, r2.W, 3), dtype=torch.float32, device="cuda")
+                for i in range(2):
+                    r2.dev.render_device(r2.cam, d2.data_ptr(), seed=seed0 + i, stream=stream)
+                torch.cuda.synchronize()
+                n2 = 3
+                t0 = time.perf_counter()
+                for i in range(n2):
+                    r2.dev.render_device(r2.cam, d2.data_ptr(), seed=seed0 + 2 + i, stream=stream)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / n2 * 1e3
+                st2 = ctx.stats()
+                entry = {"workload": r2.label(), "value": r2.W * r2.H * r2.spp / ms / 1e3, "unit": "Msamples/s",
+                         "ms_per_step": ms, "steps": n2,
+                         "roofline": roofline_block(w, r2.wl, st2["paths"], st2["ms_total"], st2)}
+                if not args.no_cpu_baseline:
+                    entry["cpu_baseline"] = cpu_baseline(r2.scene_name, r2.width_req, r2.depth, r2.texels, cspp=csp)
+                    entry["gpu_over_cpu"] = entry["value"] / entry["cpu_baseline"]["value"]
+                out["workloads"][w] = entry
+                del d2, r2
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

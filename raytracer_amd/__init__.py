@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_GPU_PATH = os.path.join(HERE, "librt_mi355x.so")
+LIB_GPU_PATH = os.environ.get("RT_LIB_GPU") or os.path.join(HERE, "librt_mi355x.so")  # (override: A/B runs of two builds)
 LIB_HOST_PATH = os.path.join(HERE, "libraytracer_host.so")
 
 RT_OK = 0
@@ -106,7 +106,6 @@ def lib():
     L.rt_intersect.argtypes = [vp, vp, vp, C.c_uint64, vp]
     L.rt_render.argtypes = [vp, vp, C.POINTER(RtCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(RtCamera), C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
-    L.rt_render_device_noalloc.argtypes = L.rt_render_device.argtypes
     L.rt_resolve.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp]
     L.rt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp]
     L.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
@@ -116,6 +115,12 @@ def lib():
     L.rt_half_round_bits.argtypes = [C.c_float, C.c_int]
     L.rt_half_round_bits.restype = C.c_uint32
     L.rt_synchronize.argtypes = [vp]
+    if not hasattr(L, "rt_multi_init") or not hasattr(L, "rt_render_device_noalloc"):
+        if not os.environ.get("RT_LIB_GPU"):
+            raise ImportError(f"{LIB_GPU_PATH} lacks entry points of include/rt_abi.h: rebuild it")
+        _gpu = L  # an older build loaded on purpose (A/B timing): only the entry points it has are bound
+        return L
+    L.rt_render_device_noalloc.argtypes = L.rt_render_device.argtypes
     L.rt_multi_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.rt_multi_shutdown.argtypes = [vp]
     L.rt_multi_last_error.argtypes = [vp]

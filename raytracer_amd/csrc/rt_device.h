@@ -616,20 +616,19 @@ __device__ __forceinline__ void node_step_wide(const Acc& acc, TravState& ts, St
   const float INF = __builtin_inff();
   float t[4];
   int32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
-  // 24 plane distances in 12 packed FMAs: slots (0, 1) and (2, 3) pairwise
-  const f32x2 nx01 = pk_planes_entry(f32x2{ex.x, ex.y}, s.mx, s.ax), nx23 = pk_planes_entry(f32x2{ex.z, ex.w}, s.mx, s.ax);
-  const f32x2 ny01 = pk_planes_entry(f32x2{ey.x, ey.y}, s.my, s.ay), ny23 = pk_planes_entry(f32x2{ey.z, ey.w}, s.my, s.ay);
-  const f32x2 nz01 = pk_planes_entry(f32x2{ez.x, ez.y}, s.mz, s.az), nz23 = pk_planes_entry(f32x2{ez.z, ez.w}, s.mz, s.az);
-  const f32x2 fx01 = pk_planes_exit(f32x2{fx.x, fx.y}, s.mx, s.ax), fx23 = pk_planes_exit(f32x2{fx.z, fx.w}, s.mx, s.ax);
-  const f32x2 fy01 = pk_planes_exit(f32x2{fy.x, fy.y}, s.my, s.ay), fy23 = pk_planes_exit(f32x2{fy.z, fy.w}, s.my, s.ay);
-  const f32x2 fz01 = pk_planes_exit(f32x2{fz.x, fz.y}, s.mz, s.az), fz23 = pk_planes_exit(f32x2{fz.z, fz.w}, s.mz, s.az);
-#define RT_WIDE_SLOT(k, P, c)                                                                                       \
+  // (scalar FMAs here: the HBM-resident instances that walk wide nodes are bound by fetch latency and short of
+  // registers — packed pairs cost them spills: C5 69 -> 75 ms)
+  const float ix = s.mx.x, iy = s.my.x, iz = s.mz.x, ixw = s.mx.y, iyw = s.my.y, izw = s.mz.y;
+  const float nx = s.ax.x, ny = s.ay.x, nz = s.az.x, ox = s.ax.y, oy = s.ay.y, oz = s.az.y;
+#define RT_WIDE_SLOT(k, m)                                                                                          \
   {                                                                                                                 \
-    const float tn = slab_max3_zero(slab_max(nx##P.c, ny##P.c), nz##P.c);                                           \
-    const float tf = slab_min3(slab_min(fx##P.c, fy##P.c), fz##P.c, ts.tmax_w);                                     \
+    const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(ex.m, ix, -nx), __builtin_fmaf(ey.m, iy, -ny)),               \
+                                 __builtin_fmaf(ez.m, iz, -nz)), 0.f);                                              \
+    const float tf = fminf(fminf(fminf(__builtin_fmaf(fx.m, ixw, -ox), __builtin_fmaf(fy.m, iyw, -oy)),             \
+                                 __builtin_fmaf(fz.m, izw, -oz)), ts.tmax_w);                                       \
     t[k] = tn <= tf ? tn : INF;                                                                                     \
   }
-  RT_WIDE_SLOT(0, 01, x) RT_WIDE_SLOT(1, 01, y) RT_WIDE_SLOT(2, 23, x) RT_WIDE_SLOT(3, 23, y)
+  RT_WIDE_SLOT(0, x) RT_WIDE_SLOT(1, y) RT_WIDE_SLOT(2, z) RT_WIDE_SLOT(3, w)
 #undef RT_WIDE_SLOT
 #define RT_WIDE_CAS(i, j)                                  \
   {                                                        \

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float* __restrict
 // keeps up to RT_MAX_SLOTS tiles in flight (one being handed out, the others waiting for their longest paths), so
 // no lane ever idles through a tile's drain.  Per lane: path regeneration from the wave's current chunk (wave64 ballot
 // + prefix).  No path state ever touches HBM.
-#define RT_MAX_SLOTS 16
+#define RT_MAX_SLOTS 64
 #define RT_TILE_LEVELS 3
 struct FusedParams {
   uint32_t K, s_begin, s_stride, Ku;
@@ -203,6 +203,7 @@ struct FusedParams {
   // tiles from the front of the list, the partner workgroups (from_back) from its end: one 64-bit counter, low word =
   // tiles taken at the front, high word = tiles taken at the back, a claim is valid while front + back < n_tiles.
   uint32_t n_tiles, from_back;
+  uint32_t n_slots;  // tile slots per workgroup (tiles in flight), <= RT_MAX_SLOTS
   uint32_t lvl_begin[RT_TILE_LEVELS + 1], lvl_y0[RT_TILE_LEVELS], lvl_tiles_x[RT_TILE_LEVELS], lvl_shift[RT_TILE_LEVELS];
   uint32_t k0, k1;
   uint32_t stack_depth;
@@ -212,7 +213,7 @@ struct FusedParams {
   uint32_t n_cached;  // four-wide nodes each workgroup copies into LDS (KIND_*_WIDE_HALF)
 };
 // Workgroup scheduler state (LDS).  cursor: low word = next sample index (0..K) of the OPEN tile to hand out, high word =
-// (tile << 5 | slot) of that tile, RT_CUR_NONE before the first tile, RT_CUR_OPENING while a wave opens the next tile,
+// (tile << 6 | slot) of that tile, RT_CUR_NONE before the first tile, RT_CUR_OPENING while a wave opens the next tile,
 // RT_CUR_EXHAUSTED when the frame has no tiles left.
 struct WgSched {
   unsigned long long cursor;
@@ -341,8 +342,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   if (STATS) st_tk = now_cycles();
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [scheduler][tile slots][stack]
-  constexpr uint32_t S = BLOCK / 64;  // tile slots of the workgroup
-  static_assert(S <= RT_MAX_SLOTS, "more waves than tile slots");
+  const uint32_t S = fp.n_slots;  // tile slots of the workgroup
   size_t off = 0;
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
@@ -489,7 +489,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
               sp->rem[s] = n_valid * fp.K;
               sp->state[s] = 1u;
               // the opener keeps the tile's first chunk; release: the slot's words are in LDS before the cursor moves
-              cursor_store(sp, (t << 5) | s, ks);
+              cursor_store(sp, (t << 6) | s, ks);
             }
             c_slot = s; k_lo = 0;
             total = min(ks, fp.K) << (2u * c_shift);
@@ -509,7 +509,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
             // the chunk is as long as what this wave adds (sized for the tile it saw; another tile may have been opened
             // in between: then the chunk is merely longer or shorter than that tile's usual ones)
             uint32_t gx, gy, gs;
-            tile_geom(fp, chi >> 5, gx, gy, gs);
+            tile_geom(fp, chi >> 6, gx, gy, gs);
             inc = chunk_samples(fp, gs);
             c = __hip_atomic_fetch_add(&sp->cursor, (unsigned long long)inc, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
           } else if (chi != RT_CUR_EXHAUSTED && chi != RT_CUR_OPENING) {
@@ -525,8 +525,8 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
         won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
         inc = (uint32_t)__builtin_amdgcn_readfirstlane((int)inc);
         if (k < fp.K) {
-          c_slot = hi & 31u;
-          tile_geom(fp, hi >> 5, x0, y0, c_shift);
+          c_slot = hi & 63u;
+          tile_geom(fp, hi >> 6, x0, y0, c_shift);
           k_lo = k;
           total = min(inc, fp.K - k) << (2u * c_shift);
         } else if (hi == RT_CUR_EXHAUSTED) {
@@ -795,7 +795,9 @@ struct rt_ctx {
   int fused_kr = 16;
   std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
   std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
-  int fused_partner_min = 8;  // partner workgroups only for frames of at least this many Mi samples
+  int fused_partner_min = 48;  // partner workgroups only for frames of at least this many Mi samples (C2 split 1 / 2 / 4 / 8 ways:
+                               // 9.62 / 5.25 / 3.01 / 1.76 ms with them, 10.13 / 5.29 / 2.96 / 1.67 without)
+  int fused_slots = 0;  // tile slots per workgroup (0 = auto)
   int fused_tail4 = 50, fused_tail2 = 30;  // share of the frame's rows (per mille) tiled 4x4 / 2x2 at the end of the tile list
   float* cur_out = nullptr;   // output frame of the render being issued
   bool cur_partner = false;   // ... and whether partner workgroups join it
@@ -1014,6 +1016,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "fused_tail4" || k == "fused_tail2") {
     if (value < 0 || value > 400) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 0..400 (per mille of the frame's rows)");
     (k == "fused_tail4" ? ctx->fused_tail4 : ctx->fused_tail2) = (int)value;
+  } else if (k == "fused_slots") {
+    if (value < 0 || value > RT_MAX_SLOTS) return fail(ctx, RT_E_INVALID_ARG, "fused_slots must be in 0.." + std::to_string(RT_MAX_SLOTS));
+    ctx->fused_slots = (int)value;
   } else if (k == "dbg_main_cap") {
     ctx->dbg_main_cap = (int)std::max<int64_t>(0, std::min<int64_t>(value, 65536));
   } else if (k == "fused_partner_min") {
@@ -1550,28 +1555,45 @@ static int render_wavefront(rt_ctx* ctx, const rt_scene* scene, const rt_camera*
 // second copy of the scene.  The partner is a 256-thread workgroup per CU of the instance that needs no copy: the
 // four-wide binary16 tree in whatever LDS is left (all or most of its 15 KB at C2), sphere records through L1/L2.
 // It runs on a second stream and takes its tiles from the same counter.
-// Samples per chunk (what a wave claims from its workgroup's open tile at a time): about one chunk per wave and tile,
-// at most 8 sample indices (512 paths), unless overridden (option fused_ku).  Never changes the frame.
-// (C2, 100 spp: 2 -> 9.67 ms, 3 -> 9.75, 6 -> 9.53, 8 -> 9.62, 12 -> 9.63, 16 -> 9.84, 25 -> 10.97; 13 spp: 1-2 best)
-static uint32_t fused_chunk(const rt_ctx* ctx, uint32_t K, uint32_t waves) {
-  if (ctx->fused_ku > 0) return (uint32_t)std::min<int64_t>(ctx->fused_ku, std::max<uint32_t>(K, 1u));
-  return std::max<uint32_t>(1u, std::min<uint32_t>(8u, K / waves));
-}
 // LDS is allocated in granules of 1280 bytes on gfx950 (160 KiB / 128): two workgroups share a CU only if their ROUNDED
 // sizes fit together (measured: 134 432 + 28 368 B = 162 800 B did not co-reside, 134 224 + 28 592 B did).
 static size_t lds_round(size_t bytes) { return (bytes + 1279) / 1280 * 1280; }
+// Tile slots per workgroup = tiles it can have in flight (1.5 KB of LDS each).  A slot is held until its tile's LONGEST
+// path ends, long after the tile's samples are handed out, so a workgroup needs several times the slots its lanes can
+// keep busy — more when a tile holds few paths (small K) or paths run long (C5 at 16 spp, 12 waves: 12 slots 69.4 ms,
+// 16: 64.2, 24: 60.5, 32: 59.4, 48: 60.6 — each slot costs the LDS node cache 24 nodes).  `want` is what the caller
+// would like, `room` the LDS bytes it can spend; option fused_slots overrides (0 = auto).
+static uint32_t fused_slots(const rt_ctx* ctx, uint32_t want, size_t room = (size_t)1 << 30) {
+  if (ctx->fused_slots > 0) want = (uint32_t)ctx->fused_slots;
+  const uint32_t fit = (uint32_t)std::min<size_t>(room / (192 * 8), RT_MAX_SLOTS);
+  return std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(want, RT_MAX_SLOTS), fit));
+}
+// Samples per chunk (what a wave claims from its workgroup's open tile at a time).  With slots to spare (at least two
+// per wave) a wave takes a whole tile, up to 16 sample indices (1024 paths) at a time: claims are rare and the waves
+// do not wait for each other's tiles (C5, 32 slots: 1 -> 59.4 ms, 4 -> 56.9, 8 -> 55.9, 16 -> 55.7).  With one slot
+// per wave (the lean LDS-resident instance beside its partner) the waves share tiles: about one chunk per wave and
+// tile, at most 8 sample indices (C2, 100 spp: 2 -> 9.67 ms, 3 -> 9.75, 6 -> 9.53, 8 -> 9.62, 12 -> 9.63, 16 -> 9.84,
+// 25 -> 10.97; 13 spp: 1-2 best).  Option fused_ku overrides.  Never changes the frame.
+static uint32_t fused_chunk(const rt_ctx* ctx, uint32_t K, uint32_t waves, uint32_t slots, uint64_t tiles_per_wave) {
+  if (ctx->fused_ku > 0) return (uint32_t)std::min<int64_t>(ctx->fused_ku, std::max<uint32_t>(K, 1u));
+  // (whole tiles only where every wave gets dozens of them: with a handful per wave the frame ends unbalanced — C2 at
+  // 13 spp, 3.5 tiles per wave: 2.79 ms against 1.64)
+  if (slots >= 2 * waves && tiles_per_wave >= 32) return std::max<uint32_t>(1u, std::min<uint32_t>(16u, K));
+  return std::max<uint32_t>(1u, std::min<uint32_t>(8u, K / waves));
+}
 static bool partner_possible(const rt_ctx* ctx, const rt_scene* scene, size_t lds_main) {
   if (!ctx->fused_partner || !scene->half_ok || scene->view.n_nodes4 >= 32768 || scene->view.n_prims >= 32768) return false;
-  const size_t fixed = RT_SCHED_BYTES + 4 * 192 * 8 + (size_t)(scene->wide_stack + 2) * 256 * 2;
+  const size_t fixed = RT_SCHED_BYTES + (size_t)fused_slots(ctx, 4) * 192 * 8 + (size_t)(scene->wide_stack + 2) * 256 * 2;
   return lds_round(lds_main) + lds_round(fixed + 16 * 64) <= 160 * 1024;
 }
 static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams& fp_main, size_t lds_main, hipStream_t st) {
   const FusedKernel kern = k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true>;
   FusedParams fp = fp_main;  // same frame, same tile counter — taken from the other end
   fp.from_back = 1;
-  fp.Ku = fused_chunk(ctx, fp.K, 4);
   fp.stack_depth = (uint32_t)scene->wide_stack + 2u;
-  const size_t fixed = RT_SCHED_BYTES + 4 * 192 * 8 + (size_t)fp.stack_depth * 256 * 2;
+  fp.n_slots = fused_slots(ctx, 4);
+  fp.Ku = fused_chunk(ctx, fp.K, 4, fp.n_slots, 0);
+  const size_t fixed = RT_SCHED_BYTES + (size_t)fp.n_slots * 192 * 8 + (size_t)fp.stack_depth * 256 * 2;
   const size_t room = 160 * 1024 - lds_round(lds_main);  // what the main workgroup leaves on its CU (a multiple of the granule)
   fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (room - fixed) / 64);
   const size_t smem = fixed + (size_t)fp.n_cached * 64;
@@ -1609,7 +1631,8 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   const int per_cu = cached->second;
   if (per_cu < 1) return fail(ctx, RT_E_INTERNAL, "fused kernel does not fit on a CU");
   FusedParams fp = fp0;
-  fp.Ku = fused_chunk(ctx, fp.K, BLOCK / 64);
+  fp.Ku = fused_chunk(ctx, fp.K, BLOCK / 64, fp.n_slots,  // (n_slots: set by render_fused, which sizes the LDS)
+                      fp.n_tiles / ((uint64_t)ctx->n_cu * (uint64_t)per_cu * (BLOCK / 64)));
   uint32_t blocks = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)per_cu, fp.n_tiles);
   if (ctx->dbg_main_cap > 0) blocks = std::min<uint32_t>(blocks, (uint32_t)ctx->dbg_main_cap);  // diagnostic
   // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
@@ -1662,15 +1685,29 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.noise_lds = lds_noise ? 1u : 0u;
   const size_t lds_tables = lds_noise;  // material / texture records stay in HBM/L2: LDS copies bought nothing measurable
   const size_t lds_scene = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 64 + lds_tables;
-  const size_t lds_1024 = lds_scene + RT_SCHED_BYTES + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
-  const size_t lds_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_tables +
-                                  RT_SCHED_BYTES + 16 * 192 * 8 + (size_t)sdepth * 1024 * 2;
+  // LDS of the 1024-thread LDS-resident instances without their tile slots, and with the 16 (one per wave) they need
+  const size_t lds_base_1024 = lds_scene + RT_SCHED_BYTES + (size_t)sdepth * 1024 * 2;
+  const size_t lds_base_generic_1024 = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * 128 + lds_tables +
+                                       RT_SCHED_BYTES + (size_t)sdepth * 1024 * 2;
+  size_t lds_1024 = lds_base_1024 + 16 * 192 * 8;
+  size_t lds_generic_1024 = lds_base_generic_1024 + 16 * 192 * 8;
   // partner workgroups (launch_partner) join the lean spheres-in-LDS instance on frames that last long enough for a
   // second launch and its join to pay (option fused_partner_min, Mi samples)
   ctx->cur_partner = ctx->fused_partner && lean && !ctx->fused_stats && scene->spheres_only && ctx->fused_lds && small_ids &&
                      lds_1024 <= 160 * 1024 && use_resume(ctx, scene) &&
                      (uint64_t)cam->width * cam->height * K >= ((uint64_t)ctx->fused_partner_min << 20) &&
                      (uint64_t)cam->width * cam->height >= 64ull * 4 * (uint64_t)ctx->n_cu && partner_possible(ctx, scene, lds_1024);
+  // tile slots: one per wave beside partner workgroups (they get the rest of the CU's LDS), two per wave otherwise
+  fp.n_slots = 16;
+  if (!ctx->cur_partner) {
+    if (scene->spheres_only && lds_1024 <= 160 * 1024) {
+      fp.n_slots = std::max<uint32_t>(fused_slots(ctx, 32, 160 * 1024 - lds_base_1024), ctx->fused_slots > 0 ? 1u : 16u);
+      lds_1024 = lds_base_1024 + (size_t)fp.n_slots * 192 * 8;
+    } else if (!scene->spheres_only && lds_generic_1024 <= 160 * 1024) {
+      fp.n_slots = std::max<uint32_t>(fused_slots(ctx, 32, 160 * 1024 - lds_base_generic_1024), ctx->fused_slots > 0 ? 1u : 16u);
+      lds_generic_1024 = lds_base_generic_1024 + (size_t)fp.n_slots * 192 * 8;
+    }
+  }
   {
     // Tile list (FusedParams): 8x8 tiles for most of the frame, then two short bands of small tiles.  A small tile must
     // still be worth opening (>= ~200 paths): 4x4 from 12 samples per pixel on, 2x2 from 48.  Band heights in tile rows
@@ -1718,7 +1755,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     const bool wide = ctx->fused_wide != 0;
     const uint32_t sd = wide ? (uint32_t)scene->wide_stack + 2u : sdepth;
     fp.stack_depth = sd;
-    const size_t smem = RT_SCHED_BYTES + 4 * 192 * 8 + (size_t)sd * 256 * 4;
+    fp.n_slots = fused_slots(ctx, 8);
+    const size_t smem = RT_SCHED_BYTES + (size_t)fp.n_slots * 192 * 8 + (size_t)sd * 256 * 4;
     if (smem > 160 * 1024) return fail(ctx, RT_E_INTERNAL, "traversal stack does not fit in LDS");
 #define RT_GLOBAL_DISPATCH(KS, KG)                                                                                              \
     if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KS, 256, int32_t>(ctx, scene, dc, fp, smem, st);       \
@@ -1733,9 +1771,13 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     // for the instances with the noise code, 1024 otherwise.
     const bool heavy = !(scene->spheres_only && lean);  // instances compiled with RT_F_TEX_NOISE
     const uint32_t cblock = heavy ? 768u : 1024u;
-    const size_t cfixed = RT_SCHED_BYTES + (size_t)(cblock / 64) * 192 * 8 + (size_t)sd * cblock * 2;
+    // (slots before cache: 2 per wave + 8, if the stacks leave that much)
+    const size_t cbase = RT_SCHED_BYTES + (size_t)sd * cblock * 2;
+    const uint32_t cslots = cbase + 16 * 64 < 160 * 1024 ? fused_slots(ctx, 2 * (cblock / 64) + 8, 160 * 1024 - cbase - 16 * 64) : cblock / 64;
+    const size_t cfixed = cbase + (size_t)cslots * 192 * 8;
     const bool ids16 = scene->view.n_nodes4 < 32768 && scene->view.n_prims < 32768;
     if (wide && ctx->fused_half && scene->half_ok && ids16 && cfixed + 16 * 64 <= 160 * 1024) {
+      fp.n_slots = cslots;
       fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (160 * 1024 - cfixed) / 64);
       const size_t csmem = cfixed + (size_t)fp.n_cached * 64;
       if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 1024, int16_t>(ctx, scene, dc, fp, csmem, st);

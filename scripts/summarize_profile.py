@@ -1,10 +1,16 @@
-"""Summarise a gpurun_out/<tag>/ profile directory (scripts/gpu_profile.sh) into profiles/<tag>_*.{csv,json}."""
+"""Summarise a gpurun_out/<tag>/ profile directory (scripts/gpu_profile.sh) into profiles/<tag>_*.{csv,json}.
+
+    python scripts/summarize_profile.py <tag> [workload]     (workload: c2 default; also writes the
+                                                              profiles/pmc_<workload>_latest.json that bench.py reads)"""
 import collections, csv, json, os, shutil, sys
 tag = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
-out = {"command": "rocprofv3 --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline (one pass per group)",
+out = {"command": "rocprofv3 --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-workloads "
+                  "--option fused_partner=0" + ("" if workload == "c2" else " --workload " + workload) + " (one pass per group)",
+       "workload": workload,
        "kernel": None, "counters": {}}
 launches = {}
 for d in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write", "pmc_l2"):
@@ -22,9 +28,9 @@ for d in ("pmc_a", "pmc_b", "pmc_fetch", "pmc_write", "pmc_l2"):
 n_launch = max(launches.values()) if launches else 1
 out["launches_profiled"] = n_launch
 out["counters"] = {k: v / n_launch for k, v in out["counters"].items()}
-out["note"] = ("counter values are PER FRAME (sum over the profiled kernel launches, partner instance included, / "
-               "launches_profiled); rocprofv3 serialises kernels while collecting counters, so the main instance does "
-               "the whole frame there and the partner finds the work-unit counter exhausted")
+out["note"] = ("counter values are PER FRAME (sum over the profiled kernel launches / launches_profiled); rocprofv3 "
+               "serialises kernels while collecting counters, so the PMC passes run with fused_partner=0: the main "
+               "instance renders the whole frame, as it would with the partner workgroups beside it minus their share")
 c = out["counters"]
 der = {}
 if "SQ_INSTS_VALU" in c:
@@ -40,6 +46,6 @@ if "TCC_HIT_sum" in c:
     der["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1)
 out["derived"] = der
 json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
-json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
+json.dump(out, open("profiles/pmc_latest.json" if workload == "c2" else f"profiles/pmc_{workload}_latest.json", "w"), indent=1)
 print(json.dumps(der, indent=1))
 print(open(f"profiles/{tag}_kernel_stats.csv").read()[:700])
