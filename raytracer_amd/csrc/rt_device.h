@@ -992,6 +992,28 @@ __device__ __forceinline__ f3 sky(d3 d) {  // mod.rs:205-207
   return {(1.f - a) + a * 0.5f, (1.f - a) + a * 0.7f, (1.f - a) + a * 1.0f};
 }
 
+// Hit point and shading normal as the render kernels form them (geometry.rs:58-64): the point stays f64 (it is the next
+// ray's origin); the normal is only ever used by f32 shading math, so it is the f64 difference p - c scaled by an f32
+// reciprocal radius, flipped against the ray.  Also what rt_intersect reports for the production tree forms (probe_tree
+// 3 / 4), so that the parity tests hold the render path's own normal against the oracle's.
+template <class Acc>
+__device__ __forceinline__ void shading_frame(const Acc& acc, int32_t prim, d3 o, d3 d, double time, double t, d3& p, f3& n,
+                                              bool& front) {
+  p = {o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
+  if (Acc::kSpheresOnly || acc.type(prim) <= 1u) {
+    PrimGeom g = acc.sphere(prim);
+    d3 c = sphere_center(g, time);
+    n = __builtin_amdgcn_rcpf((float)g.r) * tof(p - c);
+  } else if (acc.type(prim) == 2u) {
+    const Prim& P = acc.full(prim);
+    n = {(float)P.f[9], (float)P.f[10], (float)P.f[11]};
+  } else {
+    n = -1.0f * normalize(tof(d));  // medium: the isotropic phase function ignores the normal
+  }
+  front = dot(tof(d), n) < 0.f;
+  if (!front) n = -1.0f * n;
+}
+
 // One bounce of ray_color_inner (src/camera/mod.rs:187-210) given the closest hit.
 template <uint32_t F, class Acc>
 __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const Camera& cam, d3 o, d3 d, double time,
@@ -1010,24 +1032,10 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
   }
   const Material& M = acc.mats(sc)[acc.mat(hit.prim)];
   const uint32_t kind = M.kind;
-  // hit record (geometry.rs:58-64): the point stays f64 (it is the next ray's origin); the normal is only ever
-  // used by f32 shading math, so it is formed from the f64 difference p - c scaled by an f32 reciprocal radius.
   HitRec h;
-  h.p = {o.x + hit.t * d.x, o.y + hit.t * d.y, o.z + hit.t * d.z};
   h.u = 0; h.v = 0; h.uv_valid = false;
   f3 n;
-  if (Acc::kSpheresOnly || acc.type(hit.prim) <= 1u) {
-    PrimGeom g = acc.sphere(hit.prim);
-    d3 c = sphere_center(g, time);
-    n = __builtin_amdgcn_rcpf((float)g.r) * tof(h.p - c);
-  } else if (acc.type(hit.prim) == 2u) {
-    const Prim& P = acc.full(hit.prim);
-    n = {(float)P.f[9], (float)P.f[10], (float)P.f[11]};
-  } else {
-    n = -1.0f * normalize(tof(d));  // medium: the isotropic phase function ignores the normal
-  }
-  h.front = dot(tof(d), n) < 0.f;
-  if (!h.front) n = -1.0f * n;
+  shading_frame(acc, hit.prim, o, d, time, hit.t, h.p, n, h.front);
   uint32_t r[2] = {rng_next(rng), rng_next(rng)};
   // one unit-sphere sample for whichever material needs it (Lambertian, Metal fuzz, isotropic): computed once for
   // the wave instead of once per divergent material branch

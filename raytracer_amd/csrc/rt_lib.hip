@@ -329,6 +329,39 @@ constexpr int fused_waves_per_simd(uint32_t F, int KIND, int BLOCK) {
   if (F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_WIDE_HALF && BLOCK == 256) return 5;
   return 4;
 }
+// The per-workgroup copy of the scene in LDS (instances that keep it there), or of the top of the four-wide tree
+// (instances that cache it): shared by the render kernels and by the probe kernels that walk the same structures.
+// Returns the bytes used; the caller synchronises the workgroup before the first traversal.
+template <uint32_t F, int KIND, int BLOCK>
+__device__ __forceinline__ size_t lds_scene_setup(const Scene& sc, uint32_t noise_lds, uint32_t n_cached, unsigned char* smem,
+                                                  SphereRec*& l_sph, LdsTablePtr& l_noise) {
+  size_t off = 0;
+  unsigned char* l_nodes = smem;
+  if (kind_in_lds(KIND)) {
+    off += RT_SLAB_REGION_BYTES(sc.n_nodes);
+    l_sph = reinterpret_cast<SphereRec*>(smem + off);
+    const int rec16 = KIND != KIND_GENERIC_LDS ? 4 : 8;  // record size in float4s: SphereRec 64 B / Prim 128 B
+    off += (size_t)sc.n_prims * rec16 * 16;
+    for (int i = threadIdx.x; i < sc.n_nodes; i += BLOCK) slab_node_store(l_nodes, i, sc.nodes[i]);
+    const float4* gs = KIND != KIND_GENERIC_LDS ? reinterpret_cast<const float4*>(sc.spheres)
+                                                : reinterpret_cast<const float4*>(sc.prims);
+    float4* ls = reinterpret_cast<float4*>(l_sph);
+    for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
+    if ((F & RT_F_TEX_NOISE) && noise_lds) {  // 64 KB noise jump table: 40 random 16-B lookups per noise sample
+      uint4* lt = reinterpret_cast<uint4*>(smem + off);
+      l_noise = (LdsTablePtr)(reinterpret_cast<u32x4*>(lt));
+      off += 16 * 256 * 16;
+      for (int i = threadIdx.x; i < 16 * 256; i += BLOCK) lt[i] = sc.noise_table[i];
+    }
+  }
+  if (kind_caches_top(KIND)) {
+    off += (size_t)n_cached * 64;
+    uint4* lc = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < n_cached * 4u; i += BLOCK) lc[i] = sc.nodes4h[i];
+  }
+  return off;
+}
+
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS, bool RESUME>
 __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __restrict__ camp, const FusedParams& fp, unsigned long long* __restrict__ tile_counter,
                                            float* __restrict__ out_sum, unsigned long long* __restrict__ ray_total,
@@ -343,32 +376,10 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [scheduler][tile slots][stack]
   const uint32_t S = fp.n_slots;  // tile slots of the workgroup
-  size_t off = 0;
   unsigned char* l_nodes = smem;
   SphereRec* l_sph = nullptr;
   LdsTablePtr l_noise = nullptr;
-  if (kind_in_lds(KIND)) {
-    off += RT_SLAB_REGION_BYTES(sc.n_nodes);
-    l_sph = reinterpret_cast<SphereRec*>(smem + off);
-    const int rec16 = KIND != KIND_GENERIC_LDS ? 4 : 8;  // record size in float4s: SphereRec 64 B / Prim 128 B
-    off += (size_t)sc.n_prims * rec16 * 16;
-    for (int i = threadIdx.x; i < sc.n_nodes; i += BLOCK) slab_node_store(l_nodes, i, sc.nodes[i]);
-    const float4* gs = KIND != KIND_GENERIC_LDS ? reinterpret_cast<const float4*>(sc.spheres)
-                                                : reinterpret_cast<const float4*>(sc.prims);
-    float4* ls = reinterpret_cast<float4*>(l_sph);
-    for (int i = threadIdx.x; i < sc.n_prims * rec16; i += BLOCK) ls[i] = gs[i];
-    if ((F & RT_F_TEX_NOISE) && fp.noise_lds) {  // 64 KB noise jump table: 40 random 16-B lookups per noise sample
-      uint4* lt = reinterpret_cast<uint4*>(smem + off);
-      l_noise = (LdsTablePtr)(reinterpret_cast<u32x4*>(lt));
-      off += 16 * 256 * 16;
-      for (int i = threadIdx.x; i < 16 * 256; i += BLOCK) lt[i] = sc.noise_table[i];
-    }
-  }
-  if (kind_caches_top(KIND)) {
-    off += (size_t)fp.n_cached * 64;
-    uint4* lc = reinterpret_cast<uint4*>(smem);
-    for (uint32_t i = threadIdx.x; i < fp.n_cached * 4u; i += BLOCK) lc[i] = sc.nodes4h[i];
-  }
+  size_t off = lds_scene_setup<F, KIND, BLOCK>(sc, fp.noise_lds, fp.n_cached, smem, l_sph, l_noise);
   WgSched* sched = reinterpret_cast<WgSched*>(smem + off);
   off += sizeof(WgSched);
   unsigned long long* l_acc = reinterpret_cast<unsigned long long*>(smem + off);  // [slot][pixel][channel]
@@ -739,6 +750,99 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
   }
 }
 
+// Parity probe through the PRODUCTION traversal: caller rays walk exactly what the render kernels walk — the same LDS
+// copy of the scene (KIND_*_LDS: 112-byte slab nodes addressed ref << 4, records in LDS) or the four-wide binary16 tree
+// with its top cached in LDS (KIND_*_WIDE_HALF: the partner / HBM-resident form), the same 16-bit sentinel stack, and
+// traverse_resume under the render loop's schedule: a wave keeps a pool of rays, lanes take the next ray when at least
+// `kr` are free, a traversal round hands back when fewer than `kb` lanes are unfinished (stragglers resume next round
+// beside the re-launched lanes), the node loop exits below `kn` walkers.  The hit record carries the render path's own
+// f32 shading normal and front flag (shading_frame) instead of make_hit's f64 ones; u, v as the texture code gets them.
+template <int KIND, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t features, const rt_ray* __restrict__ rays, uint32_t n,
+                                                       rt_hit* __restrict__ out, uint32_t n_cached, uint32_t kb, uint32_t kn,
+                                                       uint32_t kr, unsigned long long* __restrict__ trav_counters) {
+  typedef int16_t StackT;
+  constexpr int32_t kDone = TravDone<StackT>::v;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* l_nodes = smem;
+  SphereRec* l_sph = nullptr;
+  LdsTablePtr l_noise = nullptr;
+  size_t off = lds_scene_setup<RT_F_TEX_CHECKER, KIND, BLOCK>(sc, 0u, n_cached, smem, l_sph, l_noise);
+  off += (size_t)BLOCK * sizeof(StackT);  // guard row below the stack columns (trav_pop)
+  StackT* stack = reinterpret_cast<StackT*>(smem + off) + threadIdx.x;
+  __syncthreads();
+  typename AccOf<KIND>::type acc_init = AccOf<KIND>::make(sc, l_nodes, l_sph, l_noise);
+  if constexpr (kind_caches_top(KIND)) acc_init.n_cached = (int32_t)n_cached;
+  const typename AccOf<KIND>::type acc = acc_init;
+  const uint32_t wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, n_waves = (gridDim.x * BLOCK) >> 6;
+  // this wave's pool: a contiguous range of the caller's rays
+  const uint32_t per = (n + n_waves - 1) / n_waves;
+  uint32_t next = min(n, wave * per);
+  const uint32_t total = min(n, next + per);
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  bool active = false, fresh_lane = false, fresh = false;
+  uint32_t ray_index = 0;
+  d3 o = {0, 0, 0}, d = {0, 0, 0};
+  double time = 0;
+  PathRng rng = {0, 0};
+  int32_t t_cur = kDone, t_sp = 0, t_top = kDone, t_best_prim = -1;
+  double t_best_t = 0;
+  while (true) {
+    const unsigned long long need = __ballot(!active);
+    const uint32_t n_free = (uint32_t)__popcll(need);
+    if (n_free && (n_free >= kr || n_free == 64u) && next < total) {
+      const uint32_t j = next + wave_prefix(need);
+      if (!active && j < total) {
+        const rt_ray r = rays[j];
+        o = {r.o[0], r.o[1], r.o[2]}; d = {r.d[0], r.d[1], r.d[2]};
+        time = r.time;
+        ray_index = j;
+        rng = {j * 2654435761u + 1u, 0x9E3779B9u};  // only constant media draw (their probe hits are random)
+        active = true;
+        fresh_lane = true;
+      }
+      next = min(total, next + n_free);
+      fresh = true;
+    }
+    if (__ballot(active) == 0ull) break;  // (the pool is empty too: a wave without rays regenerates all 64 lanes)
+    TravState ts;
+    trav_ray_constants(ts, o, d);
+    if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = 0; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
+    fresh_lane = false;
+    ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
+    ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
+    traverse_resume<typename AccOf<KIND>::type, StackT, true>(acc, ts, active, features, o, d, time, RT_TMIN, stack, BLOCK, &tc,
+                                                              rng, fresh ? kb : 1u, kn);
+    t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
+    const bool ready = active && t_cur == kDone;
+    fresh = __ballot(ready) != 0ull;
+    if (ready) {
+      rt_hit ho;
+      memset(&ho, 0, sizeof(ho));
+      ho.object_id = -1;
+      if (t_best_prim >= 0) {
+        d3 p;
+        f3 nf;
+        bool front;
+        shading_frame(acc, t_best_prim, o, d, time, t_best_t, p, nf, front);
+        const HitRec h = make_hit(acc, t_best_prim, o, d, time, t_best_t, true);
+        ho.object_id = sc.prims[t_best_prim].obj;
+        ho.front_face = front ? 1 : 0;
+        ho.t = t_best_t;
+        ho.p[0] = p.x; ho.p[1] = p.y; ho.p[2] = p.z;
+        ho.n[0] = (double)nf.x; ho.n[1] = (double)nf.y; ho.n[2] = (double)nf.z;
+        ho.u = h.u; ho.v = h.v;
+      }
+      out[ray_index] = ho;
+      active = false;
+    }
+  }
+  if (trav_counters) {
+    atomicAdd(&trav_counters[0], (unsigned long long)tc.nodes);
+    atomicAdd(&trav_counters[1], (unsigned long long)tc.prims);
+  }
+}
+
 // ================================================================================================ host side
 
 // ---- fixed scratch of rt_render_device_noalloc (callers that cannot allocate: HIP graph capture, serving loops).
@@ -1011,7 +1115,7 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "fused_lds") {
     ctx->fused_lds = value ? 1 : 0;
   } else if (k == "probe_tree") {
-    if (value < 0 || value > 2) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be 0, 1 or 2");
+    if (value < 0 || value > 4) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be in 0..4");
     ctx->probe_tree = (int)value;
   } else if (k == "fused_tail4" || k == "fused_tail2") {
     if (value < 0 || value > 400) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 0..400 (per mille of the frame's rows)");
@@ -1366,15 +1470,55 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
 }
 
 // ------------------------------------------------------------------------------------------------ probe
+}  // extern "C" (templates need C++ linkage)
+// probe_tree 3: the LDS-resident form the render kernels use for scenes that fit (spheres: SlabLdsAcc, general scenes:
+// GenericLdsAcc), 1024 threads; probe_tree 4: the four-wide binary16 tree with its top cached in LDS, 256 threads (the
+// partner workgroups' form; the HBM-resident render instances walk the same nodes).
+template <int KIND, int BLOCK>
+static int launch_probe_kind(rt_ctx* ctx, const rt_scene* scene, const rt_ray* d_rays, uint32_t m, rt_hit* d_hits, size_t smem,
+                             uint32_t n_cached) {
+  auto kern = k_probe_fused<KIND, BLOCK>;
+  size_t& opted = ctx->fused_lds_opt_in[reinterpret_cast<const void*>(kern)];
+  if (smem > opted) {
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    opted = smem;
+  }
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((m + BLOCK - 1) / BLOCK, (uint32_t)ctx->n_cu));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, ctx->stream, scene->view, scene->features, d_rays, m, d_hits, n_cached,
+                     (uint32_t)ctx->fused_kb, (uint32_t)ctx->fused_kn, (uint32_t)ctx->fused_kr, ctx->d_trav);
+  HIP_TRY(ctx, hipGetLastError());
+  return RT_OK;
+}
+static int launch_probe_fused(rt_ctx* ctx, const rt_scene* scene, const rt_ray* d_rays, uint32_t m, rt_hit* d_hits) {
+  const bool ids16 = scene->view.n_nodes4 < 32768 && scene->view.n_prims < 32000 &&
+                     (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768;
+  if (!ids16) return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: probe_tree 3 / 4 need 16-bit node and primitive references");
+  if (ctx->probe_tree == 3) {
+    const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
+    const size_t rec = scene->spheres_only ? 64 : 128;
+    const size_t smem = RT_SLAB_REGION_BYTES(scene->view.n_nodes) + (size_t)scene->view.n_prims * rec + (size_t)(sdepth + 1) * 1024 * 2;
+    if (smem > 160 * 1024) return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: probe_tree 3: the scene does not fit in LDS");
+    if (scene->spheres_only) return launch_probe_kind<KIND_SPHERES_LDS, 1024>(ctx, scene, d_rays, m, d_hits, smem, 0);
+    return launch_probe_kind<KIND_GENERIC_LDS, 1024>(ctx, scene, d_rays, m, d_hits, smem, 0);
+  }
+  const uint32_t sd = (uint32_t)scene->wide_stack + 2u;
+  const size_t fixed = (size_t)(sd + 1) * 256 * 2;
+  // cache about half of the tree (at least its top node): lanes then fetch from LDS and from HBM/L2 in the same walk
+  const uint32_t n_cached = (uint32_t)std::min<size_t>(std::max<size_t>(1, (size_t)scene->view.n_nodes4 / 2), (96 * 1024 - fixed) / 64);
+  const size_t smem = fixed + (size_t)n_cached * 64;
+  if (scene->spheres_only) return launch_probe_kind<KIND_SPHERES_WIDE_HALF, 256>(ctx, scene, d_rays, m, d_hits, smem, n_cached);
+  return launch_probe_kind<KIND_GENERIC_WIDE_HALF, 256>(ctx, scene, d_rays, m, d_hits, smem, n_cached);
+}
+extern "C" {
 int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_t n, rt_hit* out_hits) {
   if (!ctx) return RT_E_INVALID_ARG;
   if (!scene || (n && (!rays || !out_hits))) return fail(ctx, RT_E_INVALID_ARG, "rt_intersect: NULL argument");
   if (n == 0) return RT_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t CH = 1u << 22;
-  if (ctx->probe_tree != 0 && scene->wide_stack + 2 > RT_STACK_DEPTH)
+  if ((ctx->probe_tree == 1 || ctx->probe_tree == 2) && scene->wide_stack + 2 > RT_STACK_DEPTH)
     return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: the four-wide tree of this scene needs a deeper stack than the probe has");
-  if (ctx->probe_tree == 2 && !scene->half_ok)
+  if ((ctx->probe_tree == 2 || ctx->probe_tree == 4) && !scene->half_ok)
     return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: scene coordinates exceed the binary16 range");
   uint64_t chunk = n < CH ? n : CH;
   rt_ray* d_rays = nullptr;
@@ -1390,9 +1534,14 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
     uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - off);
     uint32_t blocks = std::min<uint32_t>((m + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)ctx->n_cu * 8);
     if ((e = hipMemcpyAsync(d_rays, rays + off, (size_t)m * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
-    auto kern = ctx->probe_tree == 2 ? k_probe<2> : ctx->probe_tree == 1 ? k_probe<1> : k_probe<0>;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, scene->features, d_rays, m,
-                       d_hits, ctx->d_trav);
+    if (ctx->probe_tree >= 3) {
+      rc = launch_probe_fused(ctx, scene, d_rays, m, d_hits);
+      if (rc != RT_OK) { e = hipSuccess; break; }
+    } else {
+      auto kern = ctx->probe_tree == 2 ? k_probe<2> : ctx->probe_tree == 1 ? k_probe<1> : k_probe<0>;
+      hipLaunchKernelGGL(kern, dim3(blocks), dim3(RT_BLOCK), 0, ctx->stream, scene->view, scene->features, d_rays, m,
+                         d_hits, ctx->d_trav);
+    }
     ctx->probe_rays += m;
     if ((e = hipGetLastError()) != hipSuccess) { rc = RT_E_HIP; break; }
     if ((e = hipMemcpyAsync(out_hits + off, d_hits, (size_t)m * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
@@ -1400,7 +1549,7 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
   }
   (void)hipFree(d_rays);
   (void)hipFree(d_hits);
-  if (rc != RT_OK) ctx->err = std::string("rt_intersect: ") + hipGetErrorString(e);
+  if (rc != RT_OK && e != hipSuccess) ctx->err = std::string("rt_intersect: ") + hipGetErrorString(e);
   return rc;
 }
 

@@ -30,11 +30,20 @@ def pair(name, width, sampler, spp, depth):
 
 @pytest.mark.parametrize("name,width", [("cornell_box", 200), ("cornell_smoke", 160), ("final_scene_small", 200),
                                         ("final_scene", 160)])
-def test_ext_primary_hit_parity(ctx, name, width):
+@pytest.mark.parametrize("form", [0, 3, 4])  # probe_tree: 0 diagnostic, 3 / 4 the render kernels' own traversals
+def test_ext_primary_hit_parity(ctx, name, width, form):
     o, g = pair(name, width, "uniform", 1, 50)
     rays = o.primary_rays(time=0.25)
     ho = o.intersect(rays)
-    hg = g.upload(ctx).intersect(rays)
+    ctx.set_option("probe_tree", form)
+    try:
+        hg = g.upload(ctx).intersect(rays)
+    except ra.RtError as e:
+        if form == 3 and e.code == ra.RT_E_UNSUPPORTED and name == "final_scene":
+            pytest.skip("final_scene does not fit in LDS: its render instances walk form 4")
+        raise
+    finally:
+        ctx.set_option("probe_tree", 0)
     prims = g.prims()
     medium_ids = set(prims["object_id"][prims["type"] >= 3].tolist())
     # constant media scatter at random distances (one RNG draw inside hit()): exclude rays where either side
@@ -53,7 +62,7 @@ def test_ext_primary_hit_parity(ctx, name, width):
     assert both.sum() > 0.3 * len(rays)
     assert (np.abs(hg["t"][both] - ho["t"][both]) / np.abs(ho["t"][both])).max() <= 1e-5
     assert np.abs(hg["n"][both] - ho["n"][both]).max() <= 1e-5
-    assert (hg["front_face"][both] == ho["front_face"][both]).all()
+    assert (hg["front_face"][both & ~graz] == ho["front_face"][both & ~graz]).all()
     if medium_ids:
         # media are hit with comparable frequency on both sides (same physics, different random streams)
         fo = np.isin(ho["object_id"], list(medium_ids)).mean()

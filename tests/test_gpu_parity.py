@@ -44,15 +44,36 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse)
 
 
+# Which traversal rt_intersect runs (option probe_tree): 0 = the binary tree in HBM with the plain loop (diagnostic form);
+# 3 = the LDS-resident form of the render kernels (slab nodes addressed ref << 4, 16-bit sentinel stack, traverse_resume
+# under the render loop's schedule, the render path's own f32 normal); 4 = the four-wide binary16 tree with its top
+# cached in LDS (partner workgroups / HBM-resident instances), same schedule.  Forms 1 / 2: test_gpu_ext.py.
+PROBE_FORMS = [0, 3, 4]
+
+
+def probe(ctx, dev, rays, form):
+    ctx.set_option("probe_tree", form)
+    try:
+        return dev.intersect(rays)
+    except ra.RtError as e:
+        if form == 4 and e.code == ra.RT_E_UNSUPPORTED and "binary16" in str(e):
+            pytest.skip("coordinates beyond the binary16 range (composition's r = 4e7 ground): no render instance walks "
+                        "the binary16 tree on such a scene")
+        raise
+    finally:
+        ctx.set_option("probe_tree", 0)
+
+
 @pytest.mark.parametrize("name,width", [("book_cover", 400), ("composition", 320), ("two_spheres", 320),
                                         ("earth", 320), ("something_blocky", 320)])
 @pytest.mark.parametrize("time", [0.5, 0.0])
-def test_primary_hit_parity(ctx, name, width, time):
+@pytest.mark.parametrize("form", PROBE_FORMS)
+def test_primary_hit_parity(ctx, name, width, time, form):
     o, g = make_pair(name, width, "uniform", 1, 50)
     rays = o.primary_rays(n_side=1, yi=0, xi=0, time=time)
     ho = o.intersect(rays)
     dev = g.upload(ctx)
-    hg = dev.intersect(rays)
+    hg = probe(ctx, dev, rays, form)
     d = rays["d"] / np.linalg.norm(rays["d"], axis=1, keepdims=True)
     hit_o = ho["object_id"] >= 0
     cosang = np.abs(np.sum(ho["n"] * d, axis=1))
@@ -72,14 +93,17 @@ def test_primary_hit_parity(ctx, name, width, time):
     assert np.abs(hg["n"][both] - ho["n"][both]).max() <= 1e-5
     scale = np.maximum(np.linalg.norm(ho["p"][both], axis=1, keepdims=True), 1.0)
     assert (np.abs(hg["p"][both] - ho["p"][both]) / scale).max() <= 1e-5
-    assert (hg["front_face"][both] == ho["front_face"][both]).all()
+    # (the render path's front test is an f32 dot product: its sign is only meaningful off the silhouette)
+    clear = both & ~grazing if form >= 3 else both
+    assert (hg["front_face"][clear] == ho["front_face"][clear]).all()
     assert np.abs(hg["u"][both] - ho["u"][both]).max() <= 1e-5 or name != "earth"
     assert np.abs(hg["v"][both] - ho["v"][both]).max() <= 1e-5
     # in practice the f64 quadratic is (near) bit-identical
     assert rel(hg["t"][both], ho["t"][both], np.abs(ho["t"][both])).max() <= 1e-10
 
 
-def test_secondary_ray_parity_book_cover(ctx):
+@pytest.mark.parametrize("form", PROBE_FORMS)
+def test_secondary_ray_parity_book_cover(ctx, form):
     """Rays leaving surfaces (origin ON a sphere, arbitrary directions) — exercises t_min=1e-6 exclusivity."""
     o, g = make_pair("book_cover", 200, "uniform", 1, 50)
     rays = o.primary_rays(time=0.37)
@@ -93,7 +117,7 @@ def test_secondary_ray_parity_book_cover(ctx):
     sec["d"] = ho["n"][hit] + u  # the Lambertian scatter direction (materials.rs:30)
     sec["time"] = 0.37
     h2o = o.intersect(sec)
-    h2g = g.upload(ctx).intersect(sec)
+    h2g = probe(ctx, g.upload(ctx), sec, form)
     same = h2o["object_id"] == h2g["object_id"]
     d = sec["d"] / np.linalg.norm(sec["d"], axis=1, keepdims=True)
     graz_o = (h2o["object_id"] >= 0) & (np.abs(np.sum(h2o["n"] * d, axis=1)) < 1e-3)
@@ -102,6 +126,7 @@ def test_secondary_ray_parity_book_cover(ctx):
     both = same & (h2o["object_id"] >= 0)
     assert both.sum() > 100
     assert (np.abs(h2g["t"][both] - h2o["t"][both]) / np.abs(h2o["t"][both])).max() <= 1e-5
+    assert np.abs(h2g["n"][both] - h2o["n"][both]).max() <= 1e-5
 
 
 def image_parity(ctx, name, width, sampler, spp, depth, seed=1234):
