@@ -14,6 +14,14 @@
 
 namespace rtd {
 
+// Floating-point contraction is decided HERE, per source expression (a * b + c inside one expression becomes an fma),
+// not by the optimiser (hipcc's default, -ffp-contract=fast, fuses across statements as it sees fit in each place the
+// code is inlined).  Every kernel instance then rounds the shading math identically, so the instance that happens to
+// trace a path — LDS-resident main kernel or its partner workgroups, decided at run time — cannot change the frame:
+// bit-identity holds by construction, not by luck of compilation.  (The f64 geometry below is contract(off): it follows
+// the reference's operation order.)
+#pragma clang fp contract(on)
+
 // ----------------------------------------------------------------------------------------------- layout
 struct __attribute__((aligned(64))) BvhNode {  // 64 B: both child boxes + child links, one fetch per step
   float l_lo[3], l_hi[3];
@@ -496,7 +504,7 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
   if (ab) { ab[0] = alpha; ab[1] = beta; }
   return true;
 }
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
 
 // EXT constant-density medium with a convex boundary (SURVEY aX3, "The Next Week" §9 in the reference's
 // conventions): boundary entry/exit over (-inf, inf) and (t1 + 1e-4, inf); clamp to the query range; scatter
@@ -818,7 +826,7 @@ __device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 
   h.n = {sgn * h.outward.x, sgn * h.outward.y, sgn * h.outward.z};
   return h;
 }
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
 
 // ----------------------------------------------------------------------------------------------- textures
 // xoroshiro128+ short jump as a GF(2)-linear map: state' = XOR over the 16 state bytes of table[byte][value]

@@ -74,10 +74,12 @@ def test_c2_kernel_variants_agree_at_full_size(ctx, c2):
         ctx.set_option("fused_lds", 1)
         ctx.set_option("fused_half", 1)
         ctx.set_option("fused_wide", 1)
-    # same paths, separately compiled code (FMA contraction in the f32 shading differs): a handful of paths flip
+    # Same paths through four separately compiled kernel instances.  Floating-point contraction is fixed per source
+    # expression (rt_device.h: `#pragma clang fp contract(on)`), the closest hit does not depend on the tree form, and
+    # sums are integers: the frames are identical bit for bit — by construction, which is what lets the partner
+    # workgroups (a different instance, chosen per tile at run time) share a frame with the main kernel.
     for other in (b, c, d):
-        close = np.isclose(a, other, rtol=1e-4, atol=1e-3).all(axis=2).mean()
-        assert close > 0.98 and abs(a.sum() - other.sum()) < 2e-4 * a.sum()
+        assert np.array_equal(a, other)
 
 
 def test_c2_frame_statistics_against_oracle(ctx, c2):

@@ -186,13 +186,12 @@ def test_wavefront_and_fused_modes_agree(ctx):
         c = dev.render_sums(cam, seed=77)
         ctx.set_option("fused_lds", 1)
         assert st_a["paths"] == st_b["paths"] == g.width * g.height * g.spp
-        # the kernels are compiled separately (different FMA contraction in the f32 shading math), so a handful of
-        # grazing decisions differ: require the same ray count within 1e-4 and identical pixels almost everywhere
-        assert abs(st_a["rays"] - st_b["rays"]) <= 1e-4 * st_a["rays"] + 2
-        for x, y in ((a, b), (b, c)):
-            close = np.isclose(x, y, rtol=2e-5, atol=1e-4).all(axis=2)
-            assert close.mean() > 0.98, (name, close.mean())
-            assert abs(float(x.sum() - y.sum())) <= 2e-4 * float(x.sum())
+        # contraction is fixed per source expression (rt_device.h), so all kernels trace the very same paths: equal ray
+        # counts; the wavefront frame differs from the fused one only by its f32 summation (fused: 2^-40 fixed point)
+        assert st_a["rays"] == st_b["rays"]
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-4)
+        # LDS-resident and HBM-resident fused instances: identical bit for bit
+        assert np.array_equal(b, c)
         # fused frames are bit-reproducible (integer accumulation is order independent)
         assert np.array_equal(b, dev.render_sums(cam, seed=77))
         # work-unit size does not change the frame
