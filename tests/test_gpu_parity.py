@@ -200,6 +200,28 @@ def test_wavefront_and_fused_modes_agree(ctx):
         ctx.set_option("fused_ku", 0)
 
 
+def test_wavefront_material_binning_keeps_the_frame(ctx):
+    """Option wf_bin: between intersect and shade the wavefront pipeline sorts the rays by material class (wave64
+    ballot / prefix counting sort).  A path's radiance does not depend on which lane shades it: identical frames."""
+    for name, spp, depth in [("book_cover", 16, 50), ("final_scene_small", 4, 20), ("cornell_box", 9, 12)]:
+        tex = earth_texels() if name == "final_scene_small" else None
+        g = ra.Scene(name, 160, ASPECT, "uniform", spp, depth, texels=tex)
+        dev, cam = g.upload(ctx), g.camera_copy()
+        ctx.set_option("mode", 0)
+        try:
+            ctx.set_option("wf_bin", 0)
+            a = dev.render_sums(cam, seed=31)
+            rays_a = ctx.stats()["rays"]
+            ctx.set_option("wf_bin", 1)
+            b = dev.render_sums(cam, seed=31)
+            rays_b = ctx.stats()["rays"]
+        finally:
+            ctx.set_option("wf_bin", 0)
+            ctx.set_option("mode", 1)
+        assert rays_a == rays_b and a.sum() > 0
+        assert np.array_equal(a, b), name
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_converged_image_parity_both_modes(ctx, mode):
     ctx.set_option("mode", mode)
