@@ -427,15 +427,33 @@ void Camera::render(const Hittable& world, const TileSender& sender, const Rende
 // ---- checkpoint file of render_progressive: header + W*H*3 f32 sums, little-endian, written to <path>.tmp and renamed
 namespace {
 struct CheckpointHeader {
-  char magic[8];  // "RTCKPT1\0"
+  char magic[8];  // "RTCKPT2\0"
   uint64_t width, height, spp, passes, next_pass, seed, sampler_kind;
+  uint64_t scene_hash;  // FNV-1a over the flattened scene arrays and the whole rt_camera block (pose, fov, defocus,
+                        // max_depth, background): sums of another scene or camera are never resumed
 };
+uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+  const uint8_t* b = static_cast<const uint8_t*>(p);
+  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001B3ull;
+  return h;
+}
+uint64_t scene_camera_hash(const rt_scene_desc& d, const rt_camera& cam) {
+  uint64_t h = 0xCBF29CE484222325ull;
+  const uint64_t counts[4] = {d.n_prims, d.n_materials, d.n_textures, d.n_texel_bytes};
+  h = fnv1a(h, counts, sizeof(counts));
+  if (d.n_prims) h = fnv1a(h, d.prims, d.n_prims * sizeof(rt_prim));
+  if (d.n_materials) h = fnv1a(h, d.materials, d.n_materials * sizeof(rt_material));
+  if (d.n_textures) h = fnv1a(h, d.textures, d.n_textures * sizeof(rt_texture));
+  if (d.n_texel_bytes) h = fnv1a(h, d.texels, d.n_texel_bytes);
+  return fnv1a(h, &cam, sizeof(cam));
+}
 bool checkpoint_load(const std::string& path, const CheckpointHeader& want, CheckpointHeader& got, std::vector<float>& sums) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
   bool ok = std::fread(&got, sizeof(got), 1, f) == 1 && std::memcmp(got.magic, want.magic, 8) == 0 &&
             got.width == want.width && got.height == want.height && got.spp == want.spp && got.passes == want.passes &&
-            got.seed == want.seed && got.sampler_kind == want.sampler_kind && got.next_pass <= got.passes;
+            got.seed == want.seed && got.sampler_kind == want.sampler_kind && got.scene_hash == want.scene_hash &&
+            got.next_pass <= got.passes;
   if (ok) ok = std::fread(sums.data(), sizeof(float), sums.size(), f) == sums.size();
   std::fclose(f);
   return ok;
@@ -465,9 +483,10 @@ size_t Camera::render_progressive(const Hittable& world, const TileSender& sende
   const size_t n_val = image_width * image_height * 3;
   std::vector<float> sums(n_val, 0.f), pass_sums(n_val);
   CheckpointHeader hdr{};
-  std::memcpy(hdr.magic, "RTCKPT1", 8);
+  std::memcpy(hdr.magic, "RTCKPT2", 8);
   hdr.width = image_width; hdr.height = image_height; hdr.spp = spp; hdr.passes = passes; hdr.next_pass = 0;
   hdr.seed = target.seed; hdr.sampler_kind = (uint64_t)cam.sampler_kind;
+  hdr.scene_hash = scene_camera_hash(desc, cam);
   if (!checkpoint_path.empty()) {
     CheckpointHeader got{};
     std::vector<float> saved(n_val);

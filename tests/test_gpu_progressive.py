@@ -67,7 +67,7 @@ def test_checkpoint_resume_after_cancel(ctx, tmp_path):
     _, rendered, _ = g.render_progressive(ctx, passes=4, seed=11, checkpoint_path=ck, ppm_path=str(ppm),
                                           on_tile=hang_up_in_third_pass)
     assert rendered == 3 and not ppm.exists() and os.path.exists(ck)  # pass 3 was rendered + saved, then cancelled
-    assert os.path.getsize(ck) == 64 + 80 * 45 * 3 * 4 and not os.path.exists(ck + ".tmp")
+    assert os.path.getsize(ck) == 72 + 80 * 45 * 3 * 4 and not os.path.exists(ck + ".tmp")
     frame, rendered, n_msgs = g.render_progressive(ctx, passes=4, seed=11, checkpoint_path=ck, ppm_path=str(ppm))
     assert rendered == 1 and n_msgs == len(tiles) and ppm.exists()  # only the missing pass is rendered
     assert np.allclose(frame, ref, rtol=0, atol=2e-6)
@@ -77,6 +77,15 @@ def test_checkpoint_resume_after_cancel(ctx, tmp_path):
     # a checkpoint of another job (different seed) is ignored, not resumed
     frame, rendered, _ = g.render_progressive(ctx, passes=4, seed=12, checkpoint_path=ck)
     assert rendered == 4 and not np.allclose(frame, ref, atol=1e-3)
+    # nor is one of another scene, or of the same scene at another depth, with the same size / spp / passes / seed:
+    # the header carries a hash of the flattened scene and of the camera block
+    other = ra.Scene("two_spheres", 80, ASPECT, "uniform", 16, 8)
+    other_ref, _ = other.render(ctx, seed=12)
+    frame, rendered, _ = other.render_progressive(ctx, passes=4, seed=12, checkpoint_path=ck)
+    assert rendered == 4 and np.allclose(frame, other_ref, rtol=0, atol=2e-6)
+    deeper = ra.Scene("two_spheres", 80, ASPECT, "uniform", 16, 9)
+    _, rendered, _ = deeper.render_progressive(ctx, passes=4, seed=12, checkpoint_path=ck)
+    assert rendered == 4
 
 
 def test_progressive_argument_errors(ctx):
