@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define RT_ABI_VERSION 1
-#define RT_NOALLOC_MAX_PIXELS (1u << 20) /* largest frame rt_render_device_noalloc accepts (width * height) */
+#define RT_NOALLOC_MAX_PIXELS (1u << 24) /* largest frame rt_render_device_noalloc accepts (width * height) */
 
 typedef enum rt_status {
   RT_OK = 0,
@@ -199,13 +199,14 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
 
 /* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, same result bit for bit, but
- * every scratch buffer of the render (the W*H*3 u64 frame accumulators, the work-unit counter, the camera block, the
- * ray counter) lives in a fixed file-scope device array inside the library instead of memory the library allocates:
- * the call performs no hipMalloc / hipFree and creates no stream or event.  Limits: fused mode only (option "mode" = 1,
- * the default); frames of at most RT_NOALLOC_MAX_PIXELS = 2^20 pixels (24 MiB of accumulators per GPU, held from
- * library load until the process ends); larger frames return RT_E_UNSUPPORTED.  Every ctx on a GPU shares that GPU's
- * array: calls that overlap in time on one GPU race (the library clears what must start at zero, stream-ordered, at
- * the start of each call). */
+ * every scratch buffer of the render (the camera block of the frame in flight, the ray counter, the tile counter the
+ * persistent workgroups claim their tiles from, the scheduler's watchdog flag) lives in a fixed file-scope device
+ * array inside the library instead of memory the library allocates: the call performs no hipMalloc / hipFree and
+ * creates no stream or event.  Limits: fused mode only (option "mode" = 1, the default); frames of at most
+ * RT_NOALLOC_MAX_PIXELS = 2^24 pixels (covers 4K; the array is 1 KiB per GPU, held from library load until the
+ * process ends — partial sums of a tile live in LDS, so nothing frame-sized is needed); larger frames return
+ * RT_E_UNSUPPORTED.  Every ctx on a GPU shares that GPU's array: calls that overlap in time on one GPU race (the
+ * library clears what must start at zero, stream-ordered, at the start of each call). */
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
                              uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream);
 

@@ -4,7 +4,7 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 pub const RT_ABI_VERSION: c_int = 1;
-pub const RT_NOALLOC_MAX_PIXELS: u32 = 1 << 20;
+pub const RT_NOALLOC_MAX_PIXELS: u32 = 1 << 24;
 
 pub const RT_OK: c_int = 0;
 pub const RT_E_INVALID_ARG: c_int = -1;

@@ -15,7 +15,7 @@ LIB_HOST_PATH = os.path.join(HERE, "libraytracer_host.so")
 
 RT_OK = 0
 RT_E_INVALID_ARG, RT_E_HIP, RT_E_OOM, RT_E_UNSUPPORTED, RT_E_INTERNAL = -1, -2, -3, -4, -5
-RT_NOALLOC_MAX_PIXELS = 1 << 20  # include/rt_abi.h
+RT_NOALLOC_MAX_PIXELS = 1 << 24  # include/rt_abi.h
 
 # every symbol include/rt_abi.h declares
 ABI_SYMBOLS = [

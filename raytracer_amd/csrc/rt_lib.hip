@@ -916,10 +916,12 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
 // ================================================================================================ host side
 
 // ---- fixed scratch of rt_render_device_noalloc (callers that cannot allocate: HIP graph capture, serving loops).
-// One copy per GPU, held until the process ends: W*H*3 u64 frame accumulators for frames of up to RT_NOALLOC_MAX_PIXELS
-// pixels (24 MiB) + 1 KiB of control words (camera block, ray counter, unit counter).  Host code never passes the
-// array's name to a kernel: rt_init asks for its address on the ctx's device (hipGetSymbolAddress) and keeps it.
-#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_MAX_PIXELS * 3 * 8 + 1024)
+// One copy per GPU, held until the process ends: 1 KiB of control words — the camera block of the render in flight, the
+// ray counter, the two-ended tile counter and the scheduler's watchdog flag.  (Round 1 also kept a W*H*3 u64 frame
+// accumulator here, 24 MiB; since the workgroups own their tiles the partial sums live in LDS and no frame-sized
+// scratch exists.)  Host code never passes the array's name to a kernel: rt_init asks for its address on the ctx's
+// device (hipGetSymbolAddress) and keeps it.
+#define RT_NOALLOC_BYTES ((size_t)1024)
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
 static_assert(sizeof(Camera) <= 512, "camera block must fit the scratch's control area");
 
@@ -951,7 +953,6 @@ struct WorkBuffers {
 
 // Device memory a fused render needs beyond its inputs and outputs.
 struct FrameScratch {
-  unsigned long long* fbacc = nullptr;      // W*H*3 fixed-point frame accumulators
   unsigned long long* unit_counter = nullptr;  // [0] two-ended tile counter of the persistent kernel, [1] its watchdog flag
   Camera* cam = nullptr;                    // camera block of the render in flight (read with scalar loads)
   unsigned long long* ray_total = nullptr;  // rays traced (stats)
@@ -992,7 +993,6 @@ struct rt_ctx {
   const FrameScratch* fs = &own;
   const unsigned long long* last_ray_total = nullptr;  // ray counter of the last render (rt_get_stats)
   const uint32_t* last_watchdog = nullptr;             // watchdog flag of the last fused render
-  size_t fbacc_cap = 0;
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
   unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
@@ -1107,8 +1107,7 @@ int rt_init(int device_id, rt_ctx** out) {
     void* base = nullptr;
     if ((e = hipGetSymbolAddress(&base, HIP_SYMBOL(scratch))) != hipSuccess || !base) return bail("hipGetSymbolAddress(scratch)", e);
     unsigned char* b = static_cast<unsigned char*>(base);
-    ctx->fixed.fbacc = reinterpret_cast<unsigned long long*>(b);
-    unsigned char* ctl = b + (size_t)RT_NOALLOC_MAX_PIXELS * 3 * 8;
+    unsigned char* ctl = b;
     ctx->fixed.cam = reinterpret_cast<Camera*>(ctl);
     ctx->fixed.ray_total = reinterpret_cast<unsigned long long*>(ctl + 512);
     ctx->fixed.unit_counter = reinterpret_cast<unsigned long long*>(ctl + 768);
@@ -1153,7 +1152,6 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->own.ray_total) (void)hipFree(ctx->own.ray_total);
   if (ctx->own.unit_counter) (void)hipFree(ctx->own.unit_counter);
   if (ctx->own.cam) (void)hipFree(ctx->own.cam);
-  if (ctx->own.fbacc) (void)hipFree(ctx->own.fbacc);
   if (ctx->d_trav) (void)hipFree(ctx->d_trav);
   if (ctx->d_bins) (void)hipFree(ctx->d_bins);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
@@ -1974,6 +1972,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     }
     fp.lvl_begin[RT_TILE_LEVELS] = t;
     fp.n_tiles = t;
+    // (a workgroup's LDS cursor carries tile << 6 | slot in 32 bits)
+    if (t >= (1u << 26)) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: frame too large (more than 2^26 tiles)");
     fp.from_back = 0;
   }
   StageTimer tm(ctx, st);
@@ -2053,7 +2053,7 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* scene, const rt_camer
     if (ctx->mode != 1)
       return fail(ctx, RT_E_UNSUPPORTED, "rt_render_device_noalloc: only the fused mode (option mode = 1) runs without allocating");
     if (n_pix > RT_NOALLOC_MAX_PIXELS)
-      return fail(ctx, RT_E_UNSUPPORTED, "rt_render_device_noalloc: frame of " + std::to_string(n_pix) + " pixels exceeds the fixed scratch (" +
+      return fail(ctx, RT_E_UNSUPPORTED, "rt_render_device_noalloc: frame of " + std::to_string(n_pix) + " pixels exceeds the stated maximum (" +
                                              std::to_string(RT_NOALLOC_MAX_PIXELS) + " pixels); use rt_render_device");
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));

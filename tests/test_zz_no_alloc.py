@@ -1,9 +1,10 @@
 """rt_render_device_noalloc — the entry point that allocates nothing — against rt_render_device, through the C ABI.
 
-Both run the same kernels; the only difference is where the render's scratch (frame accumulators, unit counter,
-camera block, ray counter) lives: library-allocated memory vs the library's fixed file-scope device array.  Fused
-frames are sums of integers, so the two must agree BIT FOR BIT (the bar of the other render tests).  Two calls in a
-row, the second with a smaller frame: the array keeps the first call's contents, and the second must not see them.
+Both run the same kernels; the only difference is where the render's scratch (camera block of the frame in flight,
+tile counter, watchdog flag, ray counter) lives: library-allocated memory vs the library's fixed file-scope device
+array.  Fused frames are sums of integers, so the two must agree BIT FOR BIT (the bar of the other render tests).  Two
+calls in a row, the second with a smaller frame: the array keeps the first call's contents (a tile counter that has
+run past the first frame's tile list), and the second must not see them.
 """
 import ctypes as C
 
@@ -50,7 +51,7 @@ def test_noalloc_entry_matches_allocating_entry_twice_second_smaller():
         assert np.array_equal(got_small, ref_small)
         assert np.array_equal(got_part, ref_part)
         assert rays_big > big.width * big.height * 36  # stats come from the fixed array's ray counter
-        # the C2-class frame (1200 x 675 = 810 000 pixels <= 2^20) with the partner workgroups, both entries
+        # the C2-class frame (1200 x 675) with the partner workgroups, both entries
         c2 = ra.Scene("book_cover", 1200, ASPECT, "uniform", 4, 50)
         dev_c2, cam_c2 = c2.upload(ctx), c2.camera_copy()
         assert c2.width * c2.height <= ra.RT_NOALLOC_MAX_PIXELS
@@ -66,13 +67,13 @@ def test_noalloc_entry_rejects_what_it_cannot_hold():
     import torch
     ctx = ra.Context(0)
     try:
-        sc = ra.Scene("two_spheres", 1920, ASPECT, "uniform", 1, 8)  # 1920 x 1080 > 2^20 pixels
+        sc = ra.Scene("two_spheres", 5600, ASPECT, "uniform", 1, 8)  # 5600 x 3150 > 2^24 pixels
         assert sc.width * sc.height > ra.RT_NOALLOC_MAX_PIXELS
         dev, cam = sc.upload(ctx), sc.camera_copy()
         d = torch.zeros((sc.height, sc.width, 3), dtype=torch.float32, device="cuda")
         with pytest.raises(ra.RtError) as e:
             dev.render_device(cam, d.data_ptr(), seed=1, no_alloc=True)
-        assert e.value.code == ra.RT_E_UNSUPPORTED and "exceeds the fixed scratch" in str(e.value)
+        assert e.value.code == ra.RT_E_UNSUPPORTED and "exceeds the stated maximum" in str(e.value)
         dev.render_device(cam, d.data_ptr(), seed=1)  # the allocating entry still takes it
         ctx.synchronize()
         assert float(d.sum()) > 0
