@@ -16,6 +16,7 @@
 #include <new>
 #include <map>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/rt_abi.h"
@@ -281,7 +282,13 @@ struct FusedParams {
   uint32_t noise_lds;  // the LDS-resident instances copy the noise jump table into LDS (scene has a noise texture)
   uint32_t kr;      // regenerate only when at least kr lanes are free (or none carries a path)
   uint32_t n_cached;  // four-wide nodes each workgroup copies into LDS (KIND_*_WIDE_HALF)
+  // Tile-order feedback (render_fused): `depth_out[tile]` receives the depth class of the tile's deepest path (0: < 6
+  // bounces, 1: < 12, 2: < 24, 3: deeper); `order`, when not NULL, is the list position -> tile permutation built from
+  // the classes the previous frame of the same scene and camera recorded (deepest first).
+  const uint32_t* order;
+  unsigned char* depth_out;
 };
+#define RT_TILE_MASK 0x03FFFFFFu  // WgSched::tile: low 26 bits = tile, bits 26..28 = depth-class flags of its paths so far
 // Workgroup scheduler state (LDS).  cursor: low word = next sample index (0..K) of the OPEN tile to hand out, high word =
 // (tile << 6 | slot) of that tile, RT_CUR_NONE before the first tile, RT_CUR_OPENING while a wave opens the next tile,
 // RT_CUR_EXHAUSTED when the frame has no tiles left.
@@ -341,6 +348,32 @@ __device__ __forceinline__ unsigned long long to_fix(float v) {
 
 __global__ void k_store_camera(Camera cam, Camera* __restrict__ dst) {
   if (threadIdx.x == 0) *dst = cam;
+}
+
+// Tile-order feedback: list position -> tile, deepest depth class first, raster order inside a class (a stable counting
+// sort by one workgroup; the tile list of a 4K frame is ~130 000 entries).  cls[] is what the previous frame of this
+// view recorded (FusedParams::depth_out).  Why: a path that bounces 50 times takes ~0.25 ms however idle the GPU is
+// (50 dependent traversals of one lane); if the tile that holds it is handed out last, the whole frame waits for it.
+__global__ __launch_bounds__(1024) void k_order_tiles(const unsigned char* __restrict__ cls, uint32_t* __restrict__ order, uint32_t n) {
+  __shared__ uint32_t cnt[4][1024];
+  __shared__ uint32_t base[4];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u, i0 = min(n, t * per), i1 = min(n, i0 + per);
+  uint32_t c[4] = {0, 0, 0, 0};
+  for (uint32_t i = i0; i < i1; i++) c[3u - min(3u, (uint32_t)cls[i])]++;  // bucket 0 = deepest
+  for (int k = 0; k < 4; k++) cnt[k][t] = c[k];
+  __syncthreads();
+  if (t < 4) {  // exclusive scan of the bucket's per-thread counts
+    uint32_t run = 0;
+    for (uint32_t j = 0; j < 1024u; j++) { const uint32_t v = cnt[t][j]; cnt[t][j] = run; run += v; }
+    base[t] = run;  // bucket total for now
+  }
+  __syncthreads();
+  if (t == 0) { uint32_t run = 0; for (int k = 0; k < 4; k++) { const uint32_t v = base[k]; base[k] = run; run += v; } }
+  __syncthreads();
+  uint32_t at[4];
+  for (int k = 0; k < 4; k++) at[k] = base[k] + cnt[k][t];
+  for (uint32_t i = i0; i < i1; i++) order[at[3u - min(3u, (uint32_t)cls[i])]++] = i;
 }
 
 template <int KIND> struct AccOf;
@@ -442,6 +475,8 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
   float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
   uint64_t st_t0 = 0, st_tk = 0;
+  float st_twait = 0.f, st_nwait = 0.f;  // cycles / visits of the "nothing to hand out" polling loop
+  float st_texh = 0.f;                   // wave age when it first found the tile list used up
   if (STATS) st_tk = now_cycles();
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [scheduler][tile slots][stack]
@@ -502,6 +537,9 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       if (depth >= cam.max_depth) alive = false;  // mod.rs:195-197: black
     }
     if (!alive) {
+      // deep paths mark their tile (tile-order feedback: such tiles go first in the next frame of this view)
+      if (depth >= 6u) __hip_atomic_fetch_or(&sched->tile[lpix >> 6], depth >= 24u ? (7u << 26) : depth >= 12u ? (3u << 26) : (1u << 26),
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // one path fewer in flight for its tile.  acq_rel at workgroup scope: the adds above are in LDS before the count
       // drops, and the lane that takes it to zero sees every other wave's adds.
       const uint32_t before = __hip_atomic_fetch_sub(&sched->rem[lpix >> 6], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -518,7 +556,9 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       const int l = __ffsll((long long)fm) - 1;
       fm &= fm - 1;
       const uint32_t s = (uint32_t)__builtin_amdgcn_readlane(flush_slot, l);
-      const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched->tile[s]);
+      const uint32_t tile_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched->tile[s]);
+      const uint32_t tile = tile_word & RT_TILE_MASK;
+      if (fp.depth_out && lane == 0) fp.depth_out[tile] = (unsigned char)__popc(tile_word >> 26);
       uint32_t tx0, ty0, tsh;
       tile_geom(fp, tile, tx0, ty0, tsh);
       const uint32_t px = tx0 + (lane & ((1u << tsh) - 1u)), py = ty0 + (lane >> tsh);
@@ -555,10 +595,12 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           const uint32_t t_front = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tc64);
           const uint32_t t_back = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tc64 >> 32));
           const bool none_left = (unsigned long long)t_front + t_back >= fp.n_tiles;
-          const uint32_t t = fp.from_back ? fp.n_tiles - 1u - t_back : t_front;
+          uint32_t t = fp.from_back ? fp.n_tiles - 1u - t_back : t_front;
+          if (fp.order && !none_left) t = fp.order[t];  // (uniform address: a scalar load)
           opening = false;
           if (none_left) {
             exhausted = true;
+            if (STATS && st_texh == 0.f) st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f);
             if (lane == 0) cursor_store(sp, RT_CUR_EXHAUSTED, fp.K);
           } else {
             tile_geom(fp, t, x0, y0, c_shift);
@@ -612,6 +654,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           total = min(inc, fp.K - k) << (2u * c_shift);
         } else if (hi == RT_CUR_EXHAUSTED) {
           exhausted = true;
+          if (STATS && st_texh == 0.f) st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f);
         } else if (won) {
           opening = true;
           continue;
@@ -654,6 +697,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
         LdsSched* const sp = sched_here(sched);
         bool go = false;
         uint32_t polls = 0;
+        if (STATS) st_t0 = now_cycles();
         do {
           __builtin_amdgcn_s_sleep(8);
           if (opening) {
@@ -665,6 +709,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
             go = (uint32_t)__builtin_amdgcn_readfirstlane((int)chi) != RT_CUR_OPENING;
           }
         } while (!go && ++polls < (1u << 24));
+        if (STATS) { st_twait += (float)(now_cycles() - st_t0) * (1.0f / 64.0f); st_nwait += 1.0f / 64.0f; }
         if (!go) {
           if (lane == 0) atomicOr(reinterpret_cast<uint32_t*>(tile_counter + 1), 1u);
           break;
@@ -722,6 +767,14 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     }
     // longest wave lifetime (positive floats order like their bit patterns): against the mean, the frame's tail
     if (lane == 0) atomicMax(reinterpret_cast<int*>(&dbg[13]), __float_as_int(st_ttotal * 64.0f));
+    {
+      float w[2] = {st_twait, st_texh};
+      for (int k = 0; k < 2; k++) {
+        float x = w[k];
+        for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
+        if (lane == 0) atomicAdd(&dbg[14 + k], x);
+      }
+    }
   }
 }
 
@@ -938,6 +991,7 @@ struct rt_scene {
   SphereRec* d_spheres = nullptr;
   Scene view{};
   int bvh_depth = 0;
+  uint64_t serial = 0;       // unique per upload (tile-order feedback recognises "the same scene" by it)
   uint32_t features = 0;     // RT_F_* of what the scene contains
   bool spheres_only = false;
 };
@@ -997,6 +1051,14 @@ struct rt_ctx {
   unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
   uint32_t* d_bins = nullptr;  // wavefront material binning: class totals [0..5], class cursors [8..13]
+  // tile-order feedback (render_fused / k_order_tiles): depth classes the last fused frame recorded per tile, the list
+  // order built from them, and what that frame looked at
+  int fused_feedback = 1;
+  unsigned char* d_tile_class = nullptr;
+  uint32_t* d_tile_order = nullptr;
+  size_t tile_cap = 0;
+  bool fb_valid = false;
+  uint64_t fb_key = 0;
   int wf_bin = 0;              // wavefront mode: sort rays by material class before shading.  Off by default: measured on
                                // C2 (100 spp in one pass, 216 M rays) it takes 9.2 ms off k_shade (36.7 -> 27.5 ms)
                                // and costs 6.3 ms of sorting + 3.1 ms of class counting in k_intersect: 57.6 vs 57.4 ms;
@@ -1149,6 +1211,8 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_work(ctx);
   if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+  if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
+  if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
   if (ctx->own.ray_total) (void)hipFree(ctx->own.ray_total);
   if (ctx->own.unit_counter) (void)hipFree(ctx->own.unit_counter);
   if (ctx->own.cam) (void)hipFree(ctx->own.cam);
@@ -1204,6 +1268,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_slots = (int)value;
   } else if (k == "dbg_main_cap") {
     ctx->dbg_main_cap = (int)std::max<int64_t>(0, std::min<int64_t>(value, 65536));
+  } else if (k == "fused_feedback") {
+    ctx->fused_feedback = value ? 1 : 0;
+    ctx->fb_valid = false;
   } else if (k == "fused_partner_min") {
     if (value < 0 || value > 65536) return fail(ctx, RT_E_INVALID_ARG, "fused_partner_min out of range");
     ctx->fused_partner_min = (int)value;
@@ -1534,6 +1601,8 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
   try {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     rt_scene* sc = new rt_scene();
+    static std::atomic<uint64_t> next_serial{1};
+    sc->serial = next_serial.fetch_add(1);
     int rc = scene_upload_impl(ctx, desc, sc);
     if (rc != RT_OK) {
       rt_scene_free(ctx, sc);
@@ -1976,6 +2045,51 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     if (t >= (1u << 26)) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: frame too large (more than 2^26 tiles)");
     fp.from_back = 0;
   }
+  // Tile-order feedback: when the last fused frame of this context showed the same scene through the same camera with
+  // the same tile list, its tiles with deep paths are handed out first (and the partner workgroups, which take from
+  // the end of the list, get the shallow ones).  Frames are unchanged: a tile's sums do not depend on when it is rendered.
+  // Not under rt_render_device_noalloc (the lists are allocated memory).
+  fp.order = nullptr;
+  fp.depth_out = nullptr;
+  // (LDS-resident instances only: where the scene is read through the caches — C5 — handing tiles out in image order
+  // keeps neighbouring rays on neighbouring nodes and texels, and the reordered frame measured 1 % slower)
+  const bool in_lds = ctx->fused_lds && small_ids &&
+                      (scene->spheres_only ? lds_1024 <= 160 * 1024 : lds_generic_1024 <= 160 * 1024);
+  if (ctx->fused_feedback && in_lds && ctx->fs == &ctx->own) {
+    if (fp.n_tiles > ctx->tile_cap) {
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
+      if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+      ctx->d_tile_class = nullptr; ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->fb_valid = false;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_tile_class, fp.n_tiles));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_tile_order, (size_t)fp.n_tiles * sizeof(uint32_t)));
+      ctx->tile_cap = fp.n_tiles;
+    }
+    uint64_t key = 0xCBF29CE484222325ull;
+    auto mix = [&key](const void* p, size_t n) {
+      const unsigned char* b = static_cast<const unsigned char*>(p);
+      for (size_t i = 0; i < n; i++) key = (key ^ b[i]) * 0x100000001B3ull;
+    };
+    mix(&scene->serial, sizeof(scene->serial));
+    mix(cam, sizeof(*cam));
+    mix(&fp.n_tiles, sizeof(fp.n_tiles));
+    mix(fp.lvl_begin, sizeof(fp.lvl_begin)); mix(fp.lvl_y0, sizeof(fp.lvl_y0)); mix(fp.lvl_shift, sizeof(fp.lvl_shift));
+    if (ctx->fb_valid && key == ctx->fb_key) {
+      hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, st, ctx->d_tile_class, ctx->d_tile_order, fp.n_tiles);
+      fp.order = ctx->d_tile_order;
+    }
+    if (fp.order && getenv("RT_VERBOSE")) {  // diagnostic: what the previous frame recorded
+      std::vector<unsigned char> h(fp.n_tiles);
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      HIP_TRY(ctx, hipMemcpy(h.data(), ctx->d_tile_class, fp.n_tiles, hipMemcpyDeviceToHost));
+      size_t c[4] = {0, 0, 0, 0};
+      for (unsigned char v : h) c[std::min<int>(3, v)]++;
+      fprintf(stderr, "[rt] tile order from depth classes: %zu shallow, %zu (>=6), %zu (>=12), %zu (>=24) of %u tiles\n", c[0], c[1], c[2], c[3], fp.n_tiles);
+    }
+    fp.depth_out = ctx->d_tile_class;
+    ctx->fb_key = key;
+    ctx->fb_valid = true;
+  }
   StageTimer tm(ctx, st);
   tm.begin();
   if (ctx->fused_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
@@ -2128,14 +2242,17 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     unsigned long long rays = 0;
     HIP_TRY(ctx, hipMemcpy(&rays, ctx->last_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
     ctx->stats.rays = rays;
-    HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 14 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
     ctx->stats.dbg[11] = ctx->mode == 0 ? ctx->ms_bin : ctx->stats.dbg[11];
     if (ctx->last_watchdog) {
+      // (instrumented build: dbg[14] / dbg[15] = wave cycles spent polling for work / visits of that loop, from the kernel)
       // tiles the main workgroups took from the front of the list / the partner workgroups from its end (diagnostic)
       uint32_t taken[2] = {0, 0};
       HIP_TRY(ctx, hipMemcpy(taken, ctx->last_watchdog - 2, sizeof(taken), hipMemcpyDeviceToHost));
-      ctx->stats.dbg[14] = (float)taken[0];
-      ctx->stats.dbg[15] = (float)taken[1];
+      if (!ctx->fused_stats) {
+        ctx->stats.dbg[14] = (float)taken[0];
+        ctx->stats.dbg[15] = (float)taken[1];
+      }
       uint32_t flag = 0;
       HIP_TRY(ctx, hipMemcpy(&flag, ctx->last_watchdog, sizeof(flag), hipMemcpyDeviceToHost));
       if (flag) return fail(ctx, RT_E_INTERNAL, "fused kernel: a wave found no work for seconds and gave up (scheduler watchdog); the frame is incomplete");

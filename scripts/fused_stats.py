@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as ra
 
 ctx = ra.Context(0)
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("--") and "=" not in a]
+for a in sys.argv[1:]:
+    if "=" in a and not a.startswith("--"):
+        ctx.set_option(a.split("=")[0], int(a.split("=")[1]))
 spp = int(args[0]) if args else 100
 scene_name = next((a.split("=")[1] for a in sys.argv if a.startswith("--scene=")), "book_cover")
 width = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--width=")), 1200))
@@ -39,6 +42,11 @@ def run(stats, **opts):
                       "lane_util": round(lane / (64 * wave), 3) if wave else None}
         if d[12] > 0:  # cycle shares of the phases (s_memtime deltas, per wave)
             out["cycles"] = {n: round(d[8 + i] / d[12], 3) for i, n in enumerate(["node", "leaf", "shade", "regen"])}
+            out["cycles"]["wait_for_work"] = round(d[14] / d[12], 3)
+            out["mean_exhaustion_age_over_max_lifetime"] = round(d[15] / 4096 / d[13], 3)
+            # mean wave lifetime over the longest one: what the frame's tail costs
+            n_waves = 4096
+            out["mean_over_max_lifetime"] = round(d[12] / n_waves / d[13], 3)
     print(json.dumps(out), flush=True)
 
 

@@ -222,6 +222,38 @@ def test_wavefront_material_binning_keeps_the_frame(ctx):
         assert np.array_equal(a, b), name
 
 
+def test_tile_order_feedback_keeps_the_frame(ctx):
+    """Option fused_feedback (default on): a fused frame records, per tile, how deep its deepest path went, and the next
+    frame of the same scene through the same camera hands the deep tiles out first (k_order_tiles).  A tile's sums do
+    not depend on when it is rendered: the reordered frame is the first one bit for bit, with another seed too, and a
+    change of camera simply falls back to image order."""
+    for name, spp, depth in [("book_cover", 16, 50), ("cornell_box", 9, 12), ("something_blocky", 4, 20)]:
+        g = ra.Scene(name, 200, ASPECT, "uniform", spp, depth)
+        dev, cam = g.upload(ctx), g.camera_copy()
+        ctx.set_option("fused_feedback", 0)
+        try:
+            want7, want8 = dev.render_sums(cam, seed=7), dev.render_sums(cam, seed=8)
+            rays7 = ctx.stats()["rays"]
+        finally:
+            ctx.set_option("fused_feedback", 1)  # (switching the option forgets what was recorded)
+        first = dev.render_sums(cam, seed=7)    # image order, records the depth classes
+        second = dev.render_sums(cam, seed=7)   # reordered by them
+        third = dev.render_sums(cam, seed=8)    # ... and by the second frame's
+        assert np.array_equal(first, want7) and np.array_equal(second, want7) and np.array_equal(third, want8), name
+        assert ctx.stats()["rays"] > 0 and want7.sum() > 0 and rays7 > 0
+        cam2 = g.camera_copy()
+        cam2.center[1] += 0.25                   # another view: the recorded classes are not used
+        moved = dev.render_sums(cam2, seed=7)
+        ctx.set_option("fused_feedback", 0)
+        try:
+            assert np.array_equal(moved, dev.render_sums(cam2, seed=7)), name
+        finally:
+            ctx.set_option("fused_feedback", 1)
+        # split frames (multi-GPU residue classes) through the reordered list
+        parts = sum(dev.render_sums(cam, seed=7, sample_begin=r, sample_stride=3).astype(np.float64) for r in range(3))
+        assert np.allclose(parts, want7, rtol=1e-6, atol=1e-6), name
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_converged_image_parity_both_modes(ctx, mode):
     ctx.set_option("mode", mode)
