@@ -232,13 +232,14 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * that do not fit LDS: 1 = four-wide tree / its binary16 form with the top levels cached in LDS, defaults; 0 = the
  * binary tree / f32 planes, kept as cross-checks), "fused_tail4" / "fused_tail2" (height, in per mille of the frame's rows, of the bands of 4x4 / 2x2 tiles at the
  * end of the tile list that keep the frame's tail short; 50 / 30; never changes the frame), "fused_slots" (tiles a workgroup keeps in flight,
- * 0 = auto), "fused_partner_min" (partner workgroups from this many Mi samples per frame), "fused_partner" (1 = default: sphere scenes resident in LDS get a second, 256-thread
+ * 0 = auto), "fused_partner_min" (partner workgroups from this many Mi samples per frame), "fused_feedback" (1 = default: a frame of
+ * the same scene and camera as the last one hands out first the tiles whose paths went deepest then; frames unchanged), "fused_partner" (1 = default: sphere scenes resident in LDS get a second, 256-thread
  * workgroup per CU of the HBM-resident instance; the frame is unchanged), "probe_tree" (which traversal rt_intersect runs: 0 the binary tree in HBM, plain loop, default;
  * 1 four-wide f32; 2 four-wide binary16; 3 and 4 the PRODUCTION forms under the render loop's own schedule — resumable
  * traversals, 16-bit sentinel stack — 3 = the scene copied into LDS as the render kernels keep it (slab nodes), 4 = the
  * four-wide binary16 tree with its top cached in LDS (partner workgroups / HBM-resident instances); with 3 and 4 rt_hit.n
- * and rt_hit.front_face are the render path's own f32 shading normal and front test), "fused_stats" (1 = instrumented kernel, fills rt_stats.dbg).  Thresholds and unit size never change the frame; the kernel variants agree up to
- * the f32 rounding of separately compiled shading code.  Unknown keys and out-of-range values
+ * and rt_hit.front_face are the render path's own f32 shading normal and front test), "fused_stats" (1 = instrumented kernel, fills rt_stats.dbg).  Thresholds, unit size and tile order never change the frame, and
+ * the kernel variants give bit-identical frames (FP contraction is fixed per source expression in all device code).  Unknown keys and out-of-range values
  * return RT_E_INVALID_ARG.  No reference counterpart (constants are edited in main.rs:28-43). */
 int rt_set_option(rt_ctx* ctx, const char* key, int64_t value);
 
