@@ -565,7 +565,7 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
 template <class StackT> struct TravDone { static constexpr int32_t v = sizeof(StackT) == 2 ? -32768 : RT_DONE; };
 struct TravState {
   int32_t cur;  // >= 0 inner node, < 0 leaf (~prim), TravDone<StackT>::v finished
-  int32_t sp;   // entries of the stack held in LDS (the one above them is cached in `top`)
+  int32_t sp;   // LDS byte address of the lane's next free stack entry (entries below it are held in LDS, the one above them is cached in `top`)
   int32_t top;  // top-of-stack kept in a register: a pop never waits on LDS (its refill load overlaps the next step)
   int32_t best_prim;
   float tmax_w;  // f32 upper bound of best_t, widened: ru(best_t) * RT_SLAB_WIDEN + 1e-30
@@ -580,36 +580,46 @@ __device__ __forceinline__ void trav_ray_constants(TravState& ts, d3 o, d3 d) {
   ts.s = make_slab(o, d);
 }
 // the part that records progress: current node, stack, best hit so far
-__device__ __forceinline__ void trav_restart(TravState& ts, int32_t root, int32_t done) {
+// LDS address <-> pointer (the traversal stacks live in LDS in every kernel; the stack pointer is kept as the 32-bit
+// address itself, so that a push or a pop needs no address arithmetic beyond its own increment)
+template <class T> __device__ __forceinline__ int32_t lds_addr(T* p) {
+  return (int32_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) T*)p;
+}
+template <class T> __device__ __forceinline__ __attribute__((address_space(3))) T* lds_ptr(int32_t a) {
+  return (__attribute__((address_space(3))) T*)(uintptr_t)(uint32_t)a;
+}
+__device__ __forceinline__ void trav_restart(TravState& ts, int32_t root, int32_t done, int32_t stack_addr) {
   ts.cur = root;
-  ts.sp = 0;
+  ts.sp = stack_addr;
   ts.top = done;
   ts.best_prim = -1;
   ts.best_t = __builtin_inf();
   ts.tmax_w = __builtin_inff();
 }
-__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, int32_t done, d3 o, d3 d) {
-  trav_restart(ts, root, done);
+__device__ __forceinline__ void trav_init(TravState& ts, int32_t root, int32_t done, int32_t stack_addr, d3 o, d3 d) {
+  trav_restart(ts, root, done, stack_addr);
   trav_ray_constants(ts, o, d);
 }
-// Stack with its top entry cached in a register and a sentinel at the bottom.  `sp` counts the entries held in LDS
-// (row k of the lane's column = entry k); the register `top` is the entry above them.  A fresh traversal starts with
-// sp = 0 and top = the "finished" marker, so the first push parks that marker in row 0 and the pop that empties the
-// stack brings it back as the current node: no emptiness test anywhere.  A pop with sp = 0 (the traversal's last) reads
+// Stack with its top entry cached in a register and a sentinel at the bottom.  `sp` is the LDS address of the lane's
+// next free entry (row k of the lane's column = entry k, rows `stride` entries apart); the register `top` is the entry
+// above the stored ones.  A fresh traversal starts with
+// sp = the column's first row and top = the "finished" marker, so the first push parks that marker in row 0 and the pop that empties the
+// stack brings it back as the current node: no emptiness test anywhere.  A pop from the empty stack (the traversal's last) reads
 // the row BELOW the column's first — the kernels keep readable LDS there (k_fused: the tile accumulators; the probe
 // kernels: a guard row) — and leaves a dead `top` that the next restart overwrites.
-// Push: one LDS store + one add; pop: one add + one LDS load (was 5 / 8 VALU instructions with clamps and a select).
+// Push: one LDS store + one add; pop: one add + one LDS load — no multiply by the row stride (768-thread workgroups:
+// a quarter-rate v_mad_u64_u32 per push before) and no shift-add.
 template <class StackT>
-__device__ __forceinline__ void trav_push(TravState& ts, int32_t v, StackT* stack, int stride) {
-  stack[ts.sp * stride] = (StackT)ts.top;
+__device__ __forceinline__ void trav_push(TravState& ts, int32_t v, StackT*, int stride) {
+  *lds_ptr<StackT>(ts.sp) = (StackT)ts.top;
   ts.top = v;
-  ts.sp++;
+  ts.sp += stride * (int)sizeof(StackT);
 }
 template <class StackT>
-__device__ __forceinline__ void trav_pop(TravState& ts, StackT* stack, int stride) {
+__device__ __forceinline__ void trav_pop(TravState& ts, StackT*, int stride) {
   ts.cur = ts.top;
-  ts.sp--;
-  ts.top = (int32_t)stack[ts.sp * stride];
+  ts.sp -= stride * (int)sizeof(StackT);
+  ts.top = (int32_t)*lds_ptr<StackT>(ts.sp);
 }
 // One step through a four-wide node: test the four boxes, continue with the nearest one hit and push the others
 // farthest first (5-exchange sorting network on (entry distance, link) pairs).  Unused slots carry an inverted
@@ -725,7 +735,7 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
                                             double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng) {
   constexpr int32_t kDone = TravDone<StackT>::v;
   TravState ts;
-  trav_init(ts, root, kDone, o, d);
+  trav_init(ts, root, kDone, lds_addr(stack), o, d);
   while (ts.cur != kDone) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();

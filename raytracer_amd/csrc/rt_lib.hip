@@ -475,7 +475,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
   float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
   uint64_t st_t0 = 0, st_tk = 0;
-  float st_twait = 0.f, st_nwait = 0.f;  // cycles / visits of the "nothing to hand out" polling loop
+  float st_twait = 0.f;                  // cycles in the "nothing to hand out" polling loop
   float st_texh = 0.f;                   // wave age when it first found the tile list used up
   if (STATS) st_tk = now_cycles();
   extern __shared__ __align__(16) unsigned char smem[];
@@ -517,7 +517,8 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   // neighbours; the per-ray constants are recomputed each round (unconditionally, so that they are not live across
   // the shading code)
   constexpr int32_t kDone = TravDone<StackT>::v;
-  int32_t t_cur = kDone, t_sp = 0, t_top = kDone, t_best_prim = -1;
+  const int32_t stack_addr = lds_addr(stack);  // the lane's stack column (LDS byte address of its first row)
+  int32_t t_cur = kDone, t_sp = stack_addr, t_top = kDone, t_best_prim = -1;
   double t_best_t = 0;
   bool fresh_lane = false;  // this lane holds a ray whose traversal has not started
   bool fresh = false;       // wave-uniform: some lane received a new ray since the last traversal call
@@ -709,7 +710,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
             go = (uint32_t)__builtin_amdgcn_readfirstlane((int)chi) != RT_CUR_OPENING;
           }
         } while (!go && ++polls < (1u << 24));
-        if (STATS) { st_twait += (float)(now_cycles() - st_t0) * (1.0f / 64.0f); st_nwait += 1.0f / 64.0f; }
+        if (STATS) { st_twait += (float)(now_cycles() - st_t0) * (1.0f / 64.0f); }
         if (!go) {
           if (lane == 0) atomicOr(reinterpret_cast<uint32_t*>(tile_counter + 1), 1u);
           break;
@@ -720,7 +721,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     if (RESUME) {
       TravState ts;
       trav_ray_constants(ts, o, d);  // all lanes (garbage in lanes without a path is never used)
-      if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = 0; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
+      if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
       fresh_lane = false;
       ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
       ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
@@ -908,7 +909,8 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
   d3 o = {0, 0, 0}, d = {0, 0, 0};
   double time = 0;
   PathRng rng = {0, 0};
-  int32_t t_cur = kDone, t_sp = 0, t_top = kDone, t_best_prim = -1;
+  const int32_t stack_addr = lds_addr(stack);  // the lane's stack column (LDS byte address of its first row)
+  int32_t t_cur = kDone, t_sp = stack_addr, t_top = kDone, t_best_prim = -1;
   double t_best_t = 0;
   while (true) {
     const unsigned long long need = __ballot(!active);
@@ -930,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
     if (__ballot(active) == 0ull) break;  // (the pool is empty too: a wave without rays regenerates all 64 lanes)
     TravState ts;
     trav_ray_constants(ts, o, d);
-    if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = 0; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
+    if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
     fresh_lane = false;
     ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
     ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
