@@ -355,24 +355,33 @@ __global__ void k_store_camera(Camera cam, Camera* __restrict__ dst) {
 // view recorded (FusedParams::depth_out).  Why: a path that bounces 50 times takes ~0.25 ms however idle the GPU is
 // (50 dependent traversals of one lane); if the tile that holds it is handed out last, the whole frame waits for it.
 __global__ __launch_bounds__(1024) void k_order_tiles(const unsigned char* __restrict__ cls, uint32_t* __restrict__ order, uint32_t n) {
-  __shared__ uint32_t cnt[4][1024];
-  __shared__ uint32_t base[4];
-  const uint32_t t = threadIdx.x;
+  __shared__ uint32_t wave_tot[4][16];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint32_t per = (n + 1023u) / 1024u, i0 = min(n, t * per), i1 = min(n, i0 + per);
   uint32_t c[4] = {0, 0, 0, 0};
   for (uint32_t i = i0; i < i1; i++) c[3u - min(3u, (uint32_t)cls[i])]++;  // bucket 0 = deepest
-  for (int k = 0; k < 4; k++) cnt[k][t] = c[k];
-  __syncthreads();
-  if (t < 4) {  // exclusive scan of the bucket's per-thread counts
-    uint32_t run = 0;
-    for (uint32_t j = 0; j < 1024u; j++) { const uint32_t v = cnt[t][j]; cnt[t][j] = run; run += v; }
-    base[t] = run;  // bucket total for now
+  // exclusive prefix of every bucket's per-thread counts: inclusive scan inside the wave, then the 16 wave totals
+  uint32_t inc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t v = c[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(v, d, 64);
+      if (lane >= (uint32_t)d) v += u;
+    }
+    inc[k] = v;
+    if (lane == 63u) wave_tot[k][wave] = v;
   }
   __syncthreads();
-  if (t == 0) { uint32_t run = 0; for (int k = 0; k < 4; k++) { const uint32_t v = base[k]; base[k] = run; run += v; } }
-  __syncthreads();
-  uint32_t at[4];
-  for (int k = 0; k < 4; k++) at[k] = base[k] + cnt[k][t];
+  uint32_t at[4], base = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; w++) { const uint32_t v = wave_tot[k][w]; total += v; if (w < wave) before += v; }
+    at[k] = base + before + inc[k] - c[k];
+    base += total;
+  }
   for (uint32_t i = i0; i < i1; i++) order[at[3u - min(3u, (uint32_t)cls[i])]++] = i;
 }
 
