@@ -7,6 +7,7 @@ import torch
 import raytracer_amd as ra
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+STRIDE = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # sample stride: 8 = the share of one GPU of eight
 ctxs = [ra.Context(0), ra.Context(0)]
 host = ra.Scene("book_cover", 1200, 16 / 9, "uniform", 100, 50)
 devs = [host.upload(c) for c in ctxs]
@@ -20,7 +21,7 @@ def run(two):
     t0 = time.perf_counter()
     for i in range(2 * N):
         k = i & 1 if two else 0
-        devs[k].render_device(cam, bufs[k].data_ptr(), seed=100 + i, stream=streams[k].cuda_stream)
+        devs[k].render_device(cam, bufs[k].data_ptr(), seed=100 + i, sample_begin=0, sample_stride=STRIDE, stream=streams[k].cuda_stream)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / (2 * N) * 1e3
 
