@@ -287,6 +287,7 @@ struct FusedParams {
   // the classes the previous frame of the same scene and camera recorded (deepest first).
   const uint32_t* order;
   unsigned char* depth_out;
+  unsigned long long* timeline;  // instrumented build: [0] earliest wave start, [1] latest wave end, [2] sum of wave ends, [3] sum of the times waves found the tile list used up (wall_clock64 ticks, low 40 bits in the sums)
 };
 #define RT_TILE_MASK 0x03FFFFFFu  // WgSched::tile: low 26 bits = tile, bits 26..28 = depth-class flags of its paths so far
 // Workgroup scheduler state (LDS).  cursor: low word = next sample index (0..K) of the OPEN tile to hand out, high word =
@@ -486,7 +487,9 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   uint64_t st_t0 = 0, st_tk = 0;
   float st_twait = 0.f;                  // cycles in the "nothing to hand out" polling loop
   float st_texh = 0.f;                   // wave age when it first found the tile list used up
-  if (STATS) st_tk = now_cycles();
+  uint64_t st_abs_exh = 0;               // ... and the time itself
+  uint64_t st_wall0 = 0;
+  if (STATS) { st_tk = now_cycles(); st_wall0 = wall_clock64(); }
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS layout: [nodes][spheres] (KIND_SPHERES_LDS only) [scheduler][tile slots][stack]
   const uint32_t S = fp.n_slots;  // tile slots of the workgroup
@@ -610,7 +613,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           opening = false;
           if (none_left) {
             exhausted = true;
-            if (STATS && st_texh == 0.f) st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f);
+            if (STATS && st_texh == 0.f) { st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f); st_abs_exh = wall_clock64(); }
             if (lane == 0) cursor_store(sp, RT_CUR_EXHAUSTED, fp.K);
           } else {
             tile_geom(fp, t, x0, y0, c_shift);
@@ -664,7 +667,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           total = min(inc, fp.K - k) << (2u * c_shift);
         } else if (hi == RT_CUR_EXHAUSTED) {
           exhausted = true;
-          if (STATS && st_texh == 0.f) st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f);
+          if (STATS && st_texh == 0.f) { st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f); st_abs_exh = wall_clock64(); }
         } else if (won) {
           opening = true;
           continue;
@@ -777,6 +780,13 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     }
     // longest wave lifetime (positive floats order like their bit patterns): against the mean, the frame's tail
     if (lane == 0) atomicMax(reinterpret_cast<int*>(&dbg[13]), __float_as_int(st_ttotal * 64.0f));
+    if (fp.timeline && lane == 0) {
+      const unsigned long long t_end = wall_clock64();
+      atomicMin(&fp.timeline[0], (unsigned long long)st_wall0);
+      atomicMax(&fp.timeline[1], t_end);
+      atomicAdd(&fp.timeline[2], t_end & 0xFFFFFFFFFFull);
+      atomicAdd(&fp.timeline[3], (unsigned long long)(st_abs_exh ? st_abs_exh : t_end) & 0xFFFFFFFFFFull);
+    }
     {
       float w[2] = {st_twait, st_texh};
       for (int k = 0; k < 2; k++) {
@@ -1064,6 +1074,7 @@ struct rt_ctx {
   uint32_t* d_bins = nullptr;  // wavefront material binning: class totals [0..5], class cursors [8..13]
   // tile-order feedback (render_fused / k_order_tiles): depth classes the last fused frame recorded per tile, the list
   // order built from them, and what that frame looked at
+  unsigned long long* d_timeline = nullptr;  // instrumented build (FusedParams::timeline)
   int fused_feedback = 1;
   unsigned char* d_tile_class = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -1192,6 +1203,7 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_bins, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_timeline, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->d_dbg, 0, 16 * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMemset(ctx->d_trav, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   // noise jump table: entry [byte position i][value v] = short_jump(state with only that byte set)
@@ -1230,6 +1242,7 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->d_trav) (void)hipFree(ctx->d_trav);
   if (ctx->d_bins) (void)hipFree(ctx->d_bins);
   if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+  if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
   if (ctx->d_noise_table) (void)hipFree(ctx->d_noise_table);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -2103,7 +2116,13 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   }
   StageTimer tm(ctx, st);
   tm.begin();
-  if (ctx->fused_stats) HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
+  fp.timeline = nullptr;
+  if (ctx->fused_stats) {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0xFF, sizeof(unsigned long long), st));     // [0]: minimum
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline + 1, 0, 3 * sizeof(unsigned long long), st));
+    fp.timeline = ctx->d_timeline;
+  }
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
     if (lean && ctx->fused_stats) {
       if (use_resume(ctx, scene)) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true, true>(ctx, scene, dc, fp, lds_1024, st);
@@ -2254,6 +2273,14 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     HIP_TRY(ctx, hipMemcpy(&rays, ctx->last_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
     ctx->stats.rays = rays;
     HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
+    if (ctx->fused_stats && getenv("RT_VERBOSE")) {
+      unsigned long long tl[4];
+      HIP_TRY(ctx, hipMemcpy(tl, ctx->d_timeline, sizeof(tl), hipMemcpyDeviceToHost));
+      const double span = (double)(tl[1] - tl[0]);
+      const double n_waves = ctx->stats.dbg[13] > 0 ? (double)ctx->stats.dbg[12] : 0;  // (unused: counts come from the caller)
+      (void)n_waves;
+      fprintf(stderr, "[rt] timeline (100 MHz ticks): span %.0f, sum_end %llu, sum_exhaust %llu, start %llu\n", span, tl[2], tl[3], tl[0] & 0xFFFFFFFFFFull);
+    }
     ctx->stats.dbg[11] = ctx->mode == 0 ? ctx->ms_bin : ctx->stats.dbg[11];
     if (ctx->last_watchdog) {
       // (instrumented build: dbg[14] / dbg[15] = wave cycles spent polling for work / visits of that loop, from the kernel)
