@@ -677,10 +677,12 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
     bool hl, hr;
     slab_pair_test(ts.s, qx, qy, qz, ts.tmax_w, tl, tr, hl, hr);
     const bool left_first = tl <= tr;
-    const bool take_left = hl && (!hr || left_first);
+    // bitwise on purpose: lane masks combined on the scalar unit and ONE select (the short-circuit form compiled to two
+    // nested selects); when neither child is hit the pop overwrites `cur`
+    const bool take_right = hr & (!hl | !left_first);
     if (hl && hr) trav_push(ts, left_first ? ch.y : ch.x, stack, stride);
-    if (hl || hr) ts.cur = take_left ? ch.x : ch.y;
-    else trav_pop(ts, stack, stride);
+    ts.cur = take_right ? ch.y : ch.x;
+    if (!hl && !hr) trav_pop(ts, stack, stride);
   }
 }
 // precondition: ts.cur < 0 && ts.cur != TravDone<StackT>::v
