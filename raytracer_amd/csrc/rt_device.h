@@ -79,6 +79,11 @@ struct Scene {
   int32_t n_nodes, n_prims, n_mats, n_texs;
   int32_t root;  // >=0 node, <0 single leaf
   int32_t bvh_depth;
+  // Spheres so large that (nearly) every ray has to test them — book_cover's r = 1000 ground — are kept OUT of the tree
+  // and tested first, by all the lanes that start a ray together, instead of as one more leaf round that the wave's
+  // node-walkers sit out (global_prims_test).  The closest hit does not depend on the order of the tests.
+  int32_t n_global;
+  int32_t global_prim[2];
 };
 
 struct Camera {
@@ -442,6 +447,7 @@ struct TravCounters {
   uint32_t nodes, prims;  // per-lane node steps / leaf tests
   float wnodes, wprims;   // per-lane share of the wave's loop trips (sums to one per executed trip)
   float t_nodes, t_prims; // per-lane share of the wave's cycles in the inner-node loop / leaf section
+  uint32_t idle_leaf, idle_done, idle_free;  // node-loop trips this lane sat out: waiting at a leaf / finished, waiting for shading / without a path
 };
 __device__ __forceinline__ uint64_t now_cycles() { return __builtin_readcyclecounter(); }
 __device__ __forceinline__ float wave_share() { return 1.0f / (float)__popcll(__ballot(1)); }
@@ -727,6 +733,28 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
   trav_pop(ts, stack, stride);
 }
 
+struct GlobalPrims {
+  int32_t n, prim[2];
+};
+__device__ __forceinline__ GlobalPrims global_prims(const Scene& sc) { return {sc.n_global, {sc.global_prim[0], sc.global_prim[1]}}; }
+// precondition: ts holds a fresh traversal (trav_restart) and the ray's constants
+template <class Acc>
+__device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPrims& gp, TravState& ts, d3 o, d3 d, double time,
+                                                  double tmin) {
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    if (g < gp.n) {
+      const PrimGeom gm = acc.sphere(gp.prim[g]);
+      double t;
+      if (sphere_hit(gm, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t)) {
+        ts.best_t = t;
+        ts.best_prim = gp.prim[g];
+        ts.tmax_w = __double2float_ru(t) * RT_SLAB_WIDEN + 1e-30f;
+      }
+    }
+  }
+}
+
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
 // stack (entries `stride` elements apart => bank-conflict free).  "while-while" form: lanes walk inner
 // nodes until they hold a leaf, then the wave runs the (expensive, f64) leaf test together.
@@ -734,10 +762,12 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
 // (src/hittable/aabb.rs:48-71) + Sphere/MovingSphere::hit (geometry.rs:36-110).
 template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
-                                            double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng) {
+                                            double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng,
+                                            GlobalPrims gp = {0, {0, 0}}) {
   constexpr int32_t kDone = TravDone<StackT>::v;
   TravState ts;
   trav_init(ts, root, kDone, lds_addr(stack), o, d);
+  if (gp.n) global_prims_test(acc, gp, ts, o, d, time, tmin);
   while (ts.cur != kDone) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();
@@ -781,6 +811,10 @@ __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, b
       if (at_node) {
         if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
         node_step(acc, ts, stack, stride);
+      } else if (COUNT) {
+        if (!participating) cnt->idle_free++;
+        else if (ts.cur == kDone) cnt->idle_done++;
+        else cnt->idle_leaf++;
       }
       at_node = ts.cur >= 0;
       m_node = wave_ballot(at_node);

@@ -87,10 +87,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(Scene sc, uint32_t featu
     if (media) { rng.s0 = q.r0[i]; rng.s1 = q.r1[i]; }
     if (SPHERES)
       hit = traverse<SphereAcc, uint32_t, false>(sphere_acc(sc), sc.root, features, o, d, q.time[i], RT_TMIN,
-                                                 stack + threadIdx.x, RT_BLOCK, nullptr, rng);
+                                                 stack + threadIdx.x, RT_BLOCK, nullptr, rng, global_prims(sc));
     else
       hit = traverse<GlobalAcc, uint32_t, false>(global_acc(sc), sc.root, features, o, d, q.time[i], RT_TMIN,
-                                                 stack + threadIdx.x, RT_BLOCK, nullptr, rng);
+                                                 stack + threadIdx.x, RT_BLOCK, nullptr, rng, global_prims(sc));
     if (media) { q.r0[i] = rng.s0; q.r1[i] = rng.s1; }
     h.prim[i] = hit.prim;
     h.t[i] = hit.t;
@@ -482,7 +482,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   // The camera block (26 doubles) stays in memory: read with scalar loads where a ray is generated instead of
   // occupying ~60 SGPRs for the whole kernel (they spilled to VGPR lanes: 68 v_readlane per regeneration).
   struct { uint32_t width, height, max_depth; } cam = {camp->width, camp->height, camp->max_depth};
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0};
   float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
   uint64_t st_t0 = 0, st_tk = 0;
   float st_twait = 0.f;                  // cycles in the "nothing to hand out" polling loop
@@ -733,10 +733,12 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     if (RESUME) {
       TravState ts;
       trav_ray_constants(ts, o, d);  // all lanes (garbage in lanes without a path is never used)
+      const bool starting = fresh_lane;
       if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
       fresh_lane = false;
       ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
       ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
+      if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, o, d, time, RT_TMIN);  // the ground: all starting lanes at once
       // ---- traverse until fewer than kb lanes are unfinished (stragglers keep their progress and go on next round
       //      beside the re-launched lanes); when nothing new was launched, run to completion
       traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
@@ -759,7 +761,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       if (active) {
         my_rays++;
         HitInfo hit = traverse<typename AccOf<KIND>::type, StackT, STATS>(acc, acc.root(sc.root), F, o, d, time, RT_TMIN,
-                                                                          stack, BLOCK, &tc, rng);
+                                                                          stack, BLOCK, &tc, rng, global_prims(sc));
         if (!bounce(hit, flush_slot)) active = false;
       }
       flush_finished(flush_slot);
@@ -780,6 +782,14 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     }
     // longest wave lifetime (positive floats order like their bit patterns): against the mean, the frame's tail
     if (lane == 0) atomicMax(reinterpret_cast<int*>(&dbg[13]), __float_as_int(st_ttotal * 64.0f));
+    if (fp.timeline) {  // node-loop trips sat out, by reason
+      unsigned long long v3[3] = {tc.idle_leaf, tc.idle_done, tc.idle_free};
+      for (int k = 0; k < 3; k++) {
+        unsigned long long x = v3[k];
+        for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
+        if (lane == 0) atomicAdd(&fp.timeline[4 + k], x);
+      }
+    }
     if (fp.timeline && lane == 0) {
       const unsigned long long t_end = wall_clock64();
       atomicMin(&fp.timeline[0], (unsigned long long)st_wall0);
@@ -865,14 +875,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
   __shared__ uint32_t stack_rows[(RT_STACK_DEPTH + 1) * RT_BLOCK];  // row 0: guard row below the columns (trav_pop)
   uint32_t* const stack = stack_rows + RT_BLOCK;
   const uint32_t stride = gridDim.x * blockDim.x;
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
     const typename ProbeAcc<TREE>::type acc = ProbeAcc<TREE>::make(sc);
     PathRng rng = {i * 2654435761u + 1u, 0x9E3779B9u};  // only constant media draw (their probe hits are random)
     HitInfo hit = traverse<typename ProbeAcc<TREE>::type, uint32_t, true>(acc, acc.root(sc.root), features, o, d, r.time,
-                                                                          RT_TMIN, stack + threadIdx.x, RT_BLOCK, &tc, rng);
+                                                                          RT_TMIN, stack + threadIdx.x, RT_BLOCK, &tc, rng, global_prims(sc));
     rt_hit ho;
     memset(&ho, 0, sizeof(ho));
     ho.object_id = -1;
@@ -922,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
   const uint32_t per = (n + n_waves - 1) / n_waves;
   uint32_t next = min(n, wave * per);
   const uint32_t total = min(n, next + per);
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0};
   bool active = false, fresh_lane = false, fresh = false;
   uint32_t ray_index = 0;
   d3 o = {0, 0, 0}, d = {0, 0, 0};
@@ -951,10 +961,12 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
     if (__ballot(active) == 0ull) break;  // (the pool is empty too: a wave without rays regenerates all 64 lanes)
     TravState ts;
     trav_ray_constants(ts, o, d);
+    const bool starting = fresh_lane;
     if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
     fresh_lane = false;
     ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
     ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
+    if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, o, d, time, RT_TMIN);
     traverse_resume<typename AccOf<KIND>::type, StackT, true>(acc, ts, active, features, o, d, time, RT_TMIN, stack, BLOCK, &tc,
                                                               rng, fresh ? kb : 1u, kn);
     t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
@@ -1075,6 +1087,7 @@ struct rt_ctx {
   // tile-order feedback (render_fused / k_order_tiles): depth classes the last fused frame recorded per tile, the list
   // order built from them, and what that frame looked at
   unsigned long long* d_timeline = nullptr;  // instrumented build (FusedParams::timeline)
+  int global_prims = 1;  // scene upload: keep huge spheres out of the tree and test them first (Scene::n_global)
   int fused_feedback = 1;
   unsigned char* d_tile_class = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -1203,7 +1216,7 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_bins, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_timeline, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_timeline, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->d_dbg, 0, 16 * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMemset(ctx->d_trav, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   // noise jump table: entry [byte position i][value v] = short_jump(state with only that byte set)
@@ -1292,6 +1305,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_slots = (int)value;
   } else if (k == "dbg_main_cap") {
     ctx->dbg_main_cap = (int)std::max<int64_t>(0, std::min<int64_t>(value, 65536));
+  } else if (k == "global_prims") {
+    ctx->global_prims = value ? 1 : 0;  // (applies to scenes uploaded afterwards)
   } else if (k == "fused_feedback") {
     ctx->fused_feedback = value ? 1 : 0;
     ctx->fb_valid = false;
@@ -1470,7 +1485,40 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": unknown primitive type");
     }
   }
-  rtb::BuildResult bvh = rtb::build_bvh(boxes, RT_STACK_DEPTH);
+  // Global primitives (Scene::n_global): (moving) spheres whose box is at least a quarter of the scene's, at most two, in
+  // scenes with a tree to speak of.  They stay in the primitive tables; the tree is built over the others.
+  std::vector<int32_t> in_tree;
+  int32_t globals[2] = {0, 0};
+  int n_global = 0;
+  if (ctx->global_prims && boxes.size() >= 32) {
+    rtb::Box all = boxes[0];
+    for (const rtb::Box& b : boxes)
+      for (int a = 0; a < 3; a++) { all.lo[a] = std::min(all.lo[a], b.lo[a]); all.hi[a] = std::max(all.hi[a], b.hi[a]); }
+    auto area = [](const rtb::Box& b) {
+      const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+      return x * y + y * z + z * x;
+    };
+    const double whole = area(all);
+    for (size_t i = 0; i < boxes.size() && n_global < 2; i++)
+      if (d->prims[i].type <= RT_PRIM_MOVING_SPHERE && area(boxes[i]) >= 0.25 * whole) globals[n_global++] = (int32_t)i;
+  }
+  std::vector<rtb::Box> tree_boxes;
+  if (n_global) {
+    for (size_t i = 0; i < boxes.size(); i++)
+      if (!(n_global > 0 && (int32_t)i == globals[0]) && !(n_global > 1 && (int32_t)i == globals[1])) {
+        in_tree.push_back((int32_t)i);
+        tree_boxes.push_back(boxes[i]);
+      }
+  }
+  rtb::BuildResult bvh = rtb::build_bvh(n_global ? tree_boxes : boxes, RT_STACK_DEPTH);
+  if (n_global) {  // leaf references back to positions in the primitive tables
+    auto fix = [&in_tree](int32_t& ref) { if (ref < 0 && ref != rtb::EMPTY_CHILD) ref = ~in_tree[(size_t)~ref]; };
+    for (rtb::FlatNode& nd : bvh.nodes) { fix(nd.left); fix(nd.right); }
+    fix(bvh.root);
+  }
+  sc->view.n_global = n_global;
+  sc->view.global_prim[0] = globals[0];
+  sc->view.global_prim[1] = globals[1];
   sc->bvh_depth = bvh.depth;
   if (getenv("RT_VERBOSE"))
     fprintf(stderr, "[rt] scene: %zu prims, %zu nodes, BVH depth %d\n", boxes.size(), bvh.nodes.size(), bvh.depth);
@@ -2120,7 +2168,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   if (ctx->fused_stats) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0xFF, sizeof(unsigned long long), st));     // [0]: minimum
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline + 1, 0, 3 * sizeof(unsigned long long), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline + 1, 0, 7 * sizeof(unsigned long long), st));
     fp.timeline = ctx->d_timeline;
   }
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
@@ -2274,11 +2322,12 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     ctx->stats.rays = rays;
     HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
     if (ctx->fused_stats && getenv("RT_VERBOSE")) {
-      unsigned long long tl[4];
+      unsigned long long tl[8];
       HIP_TRY(ctx, hipMemcpy(tl, ctx->d_timeline, sizeof(tl), hipMemcpyDeviceToHost));
       const double span = (double)(tl[1] - tl[0]);
       const double n_waves = ctx->stats.dbg[13] > 0 ? (double)ctx->stats.dbg[12] : 0;  // (unused: counts come from the caller)
       (void)n_waves;
+      fprintf(stderr, "[rt] node-loop trips sat out (lane-trips): at a leaf %llu, finished %llu, no path %llu; walked %.0f\n", tl[4], tl[5], tl[6], (double)ctx->stats.dbg[0]);
       fprintf(stderr, "[rt] timeline (100 MHz ticks): span %.0f, sum_end %llu, sum_exhaust %llu, start %llu\n", span, tl[2], tl[3], tl[0] & 0xFFFFFFFFFFull);
     }
     ctx->stats.dbg[11] = ctx->mode == 0 ? ctx->ms_bin : ctx->stats.dbg[11];

@@ -222,6 +222,36 @@ def test_wavefront_material_binning_keeps_the_frame(ctx):
         assert np.array_equal(a, b), name
 
 
+def test_global_primitives_outside_the_tree_change_nothing(ctx):
+    """Option global_prims (default on, read at scene upload): spheres whose box is a quarter of the scene's — book_cover's
+    r = 1000 ground — stay out of the BVH and are tested first by every ray.  The closest hit does not depend on the
+    order of the tests: hits through every traversal form and whole frames are identical with the option on and off."""
+    o = OracleScene("book_cover", 160, ASPECT, "uniform", 1, 50)
+    rays = o.primary_rays(time=0.37)
+    g = ra.Scene("book_cover", 160, ASPECT, "uniform", 16, 50)
+    cam = g.camera_copy()
+    got = {}
+    for on in (0, 1):
+        ctx.set_option("global_prims", on)
+        try:
+            dev = g.upload(ctx)
+        finally:
+            ctx.set_option("global_prims", 1)
+        hits = [probe(ctx, dev, rays, form) for form in PROBE_FORMS]
+        frame = dev.render_sums(cam, seed=21)
+        ctx.set_option("mode", 0)
+        try:
+            wf = dev.render_sums(cam, seed=21)
+        finally:
+            ctx.set_option("mode", 1)
+        got[on] = (hits, frame, wf, ctx.stats()["rays"])
+        dev.close()
+    for a, b in zip(got[0][0], got[1][0]):
+        assert np.array_equal(a["object_id"], b["object_id"]) and np.array_equal(a["t"], b["t"])
+    assert (got[1][0][0]["object_id"] == 0).sum() > 1000  # the ground (object 0) is hit, through the up-front test
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2]) and got[0][3] == got[1][3]
+
+
 def test_tile_order_feedback_keeps_the_frame(ctx):
     """Option fused_feedback (default on): a fused frame records, per tile, how deep its deepest path went, and the next
     frame of the same scene through the same camera hands the deep tiles out first (k_order_tiles).  A tile's sums do
