@@ -739,16 +739,28 @@ struct GlobalPrims {
 __device__ __forceinline__ GlobalPrims global_prims(const Scene& sc) { return {sc.n_global, {sc.global_prim[0], sc.global_prim[1]}}; }
 // precondition: ts holds a fresh traversal (trav_restart) and the ray's constants
 template <class Acc>
-__device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPrims& gp, TravState& ts, d3 o, d3 d, double time,
-                                                  double tmin) {
+__device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPrims& gp, TravState& ts, uint32_t features, d3 o,
+                                                  d3 d, double time, double tmin, PathRng& rng) {
 #pragma unroll
   for (int g = 0; g < 2; g++) {
     if (g < gp.n) {
-      const PrimGeom gm = acc.sphere(gp.prim[g]);
+      const int32_t pi = gp.prim[g];
       double t;
-      if (sphere_hit(gm, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t)) {
+      bool h;
+      if (Acc::kSpheresOnly) {
+        h = sphere_hit(acc.sphere(pi), o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+      } else {  // a (moving) sphere or a spherical constant medium (the final scene's r = 5000 haze): uniform per g
+        const Prim& P = acc.full(pi);
+        if (P.type <= 1u) {
+          const PrimGeom gm = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, P.f[6], P.type, P.mat};
+          h = sphere_hit(gm, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+        } else {
+          h = (features & RT_F_MEDIUM) ? medium_hit(P, o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t) : false;
+        }
+      }
+      if (h) {
         ts.best_t = t;
-        ts.best_prim = gp.prim[g];
+        ts.best_prim = pi;
         ts.tmax_w = __double2float_ru(t) * RT_SLAB_WIDEN + 1e-30f;
       }
     }
@@ -767,7 +779,7 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
   constexpr int32_t kDone = TravDone<StackT>::v;
   TravState ts;
   trav_init(ts, root, kDone, lds_addr(stack), o, d);
-  if (gp.n) global_prims_test(acc, gp, ts, o, d, time, tmin);
+  if (gp.n) global_prims_test(acc, gp, ts, features, o, d, time, tmin, rng);
   while (ts.cur != kDone) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();

@@ -738,7 +738,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       fresh_lane = false;
       ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
       ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
-      if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, o, d, time, RT_TMIN);  // the ground: all starting lanes at once
+      if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, F, o, d, time, RT_TMIN, rng);  // the ground: all starting lanes at once
       // ---- traverse until fewer than kb lanes are unfinished (stragglers keep their progress and go on next round
       //      beside the re-launched lanes); when nothing new was launched, run to completion
       traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
     fresh_lane = false;
     ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
     ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
-    if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, o, d, time, RT_TMIN);
+    if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, features, o, d, time, RT_TMIN, rng);
     traverse_resume<typename AccOf<KIND>::type, StackT, true>(acc, ts, active, features, o, d, time, RT_TMIN, stack, BLOCK, &tc,
                                                               rng, fresh ? kb : 1u, kn);
     t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
@@ -1500,7 +1500,8 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     };
     const double whole = area(all);
     for (size_t i = 0; i < boxes.size() && n_global < 2; i++)
-      if (d->prims[i].type <= RT_PRIM_MOVING_SPHERE && area(boxes[i]) >= 0.25 * whole) globals[n_global++] = (int32_t)i;
+      if ((d->prims[i].type <= RT_PRIM_MOVING_SPHERE || d->prims[i].type == RT_PRIM_MEDIUM_SPHERE) && area(boxes[i]) >= 0.25 * whole)
+        globals[n_global++] = (int32_t)i;
   }
   std::vector<rtb::Box> tree_boxes;
   if (n_global) {
