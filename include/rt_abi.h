@@ -233,8 +233,8 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * binary tree / f32 planes, kept as cross-checks), "fused_tail4" / "fused_tail2" (height, in per mille of the frame's rows, of the bands of 4x4 / 2x2 tiles at the
  * end of the tile list that keep the frame's tail short; 50 / 30; never changes the frame), "fused_slots" (tiles a workgroup keeps in flight,
  * 0 = auto), "fused_partner_min" (partner workgroups from this many Mi samples per frame), "global_prims" (1 = default, read by rt_scene_upload: spheres and spherical media whose box is a quarter of the scene's are kept out of
- * the tree and tested first by every ray; hits unchanged, frames unchanged unless the primitive is a medium, whose
- * free-path draw then comes first in the ray's random stream), "fused_feedback" (1 = default: a frame of
+ * the tree and tested first by every ray, and scenes of at most 8 primitives get no tree at all; hits unchanged, frames unchanged unless the primitive is a medium, whose
+ * free-path draw then comes first in the ray's random stream), "fused_kr_sync" (regeneration threshold of the bounce-synchronous schedule, 1..64, default 8), "fused_feedback" (1 = default: a frame of
  * the same scene and camera as the last one hands out first the tiles whose paths went deepest then; frames unchanged), "fused_partner" (1 = default: sphere scenes resident in LDS get a second, 256-thread
  * workgroup per CU of the HBM-resident instance; the frame is unchanged), "probe_tree" (which traversal rt_intersect runs: 0 the binary tree in HBM, plain loop, default;
  * 1 four-wide f32; 2 four-wide binary16; 3 and 4 the PRODUCTION forms under the render loop's own schedule — resumable

@@ -82,8 +82,10 @@ struct Scene {
   // Spheres so large that (nearly) every ray has to test them — book_cover's r = 1000 ground — are kept OUT of the tree
   // and tested first, by all the lanes that start a ray together, instead of as one more leaf round that the wave's
   // node-walkers sit out (global_prims_test).  The closest hit does not depend on the order of the tests.
-  int32_t n_global;
-  int32_t global_prim[2];
+  // Scenes of at most eight primitives (the Cornell boxes) have no tree at all: every ray tests every primitive in turn,
+  // all lanes the same one — no node steps, no divergent leaf rounds (tree_empty).
+  int32_t n_global, tree_empty;
+  int32_t global_prim[8];
 };
 
 struct Camera {
@@ -691,11 +693,10 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
     if (!hl && !hr) trav_pop(ts, stack, stride);
   }
 }
-// precondition: ts.cur < 0 && ts.cur != TravDone<StackT>::v
-template <class Acc, class StackT>
-__device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_t features, d3 o, d3 d, double time,
-                                          double tmin, StackT* stack, int stride, PathRng& rng) {
-  const int32_t pi = ~ts.cur;
+// One primitive against the ray: on a hit closer than the best so far, the best hit becomes this one.
+template <class Acc>
+__device__ __forceinline__ void prim_test(const Acc& acc, TravState& ts, int32_t pi, uint32_t features, d3 o, d3 d, double time,
+                                          double tmin, PathRng& rng) {
   double t;
   bool h = false;
   if (Acc::kSpheresOnly) {
@@ -730,41 +731,37 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
     ts.best_prim = pi;
     ts.tmax_w = __double2float_ru(t) * RT_SLAB_WIDEN + 1e-30f;
   }
+}
+// precondition: ts.cur < 0 && ts.cur != TravDone<StackT>::v
+template <class Acc, class StackT>
+__device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_t features, d3 o, d3 d, double time,
+                                          double tmin, StackT* stack, int stride, PathRng& rng) {
+  prim_test(acc, ts, ~ts.cur, features, o, d, time, tmin, rng);
   trav_pop(ts, stack, stride);
 }
 
+#define RT_MAX_GLOBAL 8
 struct GlobalPrims {
-  int32_t n, prim[2];
+  int32_t n;           // primitives tested up-front, outside the tree
+  int32_t tree_empty;  // ... and they are ALL the scene's primitives (tiny scenes: no tree at all)
+  int32_t prim[RT_MAX_GLOBAL];
 };
-__device__ __forceinline__ GlobalPrims global_prims(const Scene& sc) { return {sc.n_global, {sc.global_prim[0], sc.global_prim[1]}}; }
-// precondition: ts holds a fresh traversal (trav_restart) and the ray's constants
+__device__ __forceinline__ GlobalPrims global_prims(const Scene& sc) {
+  GlobalPrims g;
+  g.n = sc.n_global;
+  g.tree_empty = sc.tree_empty;
+#pragma unroll
+  for (int k = 0; k < RT_MAX_GLOBAL; k++) g.prim[k] = sc.global_prim[k];
+  return g;
+}
+// precondition: ts holds a fresh traversal (trav_restart) and the ray's constants.  The primitive index is the same in
+// every lane, so the type dispatch inside prim_test does not diverge.
 template <class Acc>
 __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPrims& gp, TravState& ts, uint32_t features, d3 o,
                                                   d3 d, double time, double tmin, PathRng& rng) {
 #pragma unroll
-  for (int g = 0; g < 2; g++) {
-    if (g < gp.n) {
-      const int32_t pi = gp.prim[g];
-      double t;
-      bool h;
-      if (Acc::kSpheresOnly) {
-        h = sphere_hit(acc.sphere(pi), o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
-      } else {  // a (moving) sphere or a spherical constant medium (the final scene's r = 5000 haze): uniform per g
-        const Prim& P = acc.full(pi);
-        if (P.type <= 1u) {
-          const PrimGeom gm = {{P.f[0], P.f[1], P.f[2]}, {P.f[3], P.f[4], P.f[5]}, P.f[6], P.type, P.mat};
-          h = sphere_hit(gm, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
-        } else {
-          h = (features & RT_F_MEDIUM) ? medium_hit(P, o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t) : false;
-        }
-      }
-      if (h) {
-        ts.best_t = t;
-        ts.best_prim = pi;
-        ts.tmax_w = __double2float_ru(t) * RT_SLAB_WIDEN + 1e-30f;
-      }
-    }
-  }
+  for (int g = 0; g < RT_MAX_GLOBAL; g++)
+    if (g < gp.n) prim_test(acc, ts, gp.prim[g], features, o, d, time, tmin, rng);
 }
 
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
@@ -775,11 +772,12 @@ __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPr
 template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
                                             double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng,
-                                            GlobalPrims gp = {0, {0, 0}}) {
+                                            GlobalPrims gp = GlobalPrims{0, 0, {0, 0, 0, 0, 0, 0, 0, 0}}) {
   constexpr int32_t kDone = TravDone<StackT>::v;
   TravState ts;
   trav_init(ts, root, kDone, lds_addr(stack), o, d);
   if (gp.n) global_prims_test(acc, gp, ts, features, o, d, time, tmin, rng);
+  if (gp.tree_empty) ts.cur = kDone;
   while (ts.cur != kDone) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();

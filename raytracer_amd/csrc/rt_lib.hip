@@ -734,7 +734,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       TravState ts;
       trav_ray_constants(ts, o, d);  // all lanes (garbage in lanes without a path is never used)
       const bool starting = fresh_lane;
-      if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
+      if (fresh_lane) { t_cur = sc.tree_empty ? kDone : acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
       fresh_lane = false;
       ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
       ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
     TravState ts;
     trav_ray_constants(ts, o, d);
     const bool starting = fresh_lane;
-    if (fresh_lane) { t_cur = acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
+    if (fresh_lane) { t_cur = sc.tree_empty ? kDone : acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
     fresh_lane = false;
     ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
     ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
@@ -1087,6 +1087,7 @@ struct rt_ctx {
   // tile-order feedback (render_fused / k_order_tiles): depth classes the last fused frame recorded per tile, the list
   // order built from them, and what that frame looked at
   unsigned long long* d_timeline = nullptr;  // instrumented build (FusedParams::timeline)
+  int fused_kr_sync = 8;  // regeneration threshold of the bounce-synchronous schedule (small scenes)
   int global_prims = 1;  // scene upload: keep huge spheres out of the tree and test them first (Scene::n_global)
   int fused_feedback = 1;
   unsigned char* d_tile_class = nullptr;
@@ -1305,6 +1306,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_slots = (int)value;
   } else if (k == "dbg_main_cap") {
     ctx->dbg_main_cap = (int)std::max<int64_t>(0, std::min<int64_t>(value, 65536));
+  } else if (k == "fused_kr_sync") {
+    if (value < 1 || value > 64) return fail(ctx, RT_E_INVALID_ARG, "fused_kr_sync must be in 1..64");
+    ctx->fused_kr_sync = (int)value;
   } else if (k == "global_prims") {
     ctx->global_prims = value ? 1 : 0;  // (applies to scenes uploaded afterwards)
   } else if (k == "fused_feedback") {
@@ -1488,9 +1492,13 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   // Global primitives (Scene::n_global): (moving) spheres whose box is at least a quarter of the scene's, at most two, in
   // scenes with a tree to speak of.  They stay in the primitive tables; the tree is built over the others.
   std::vector<int32_t> in_tree;
-  int32_t globals[2] = {0, 0};
+  int32_t globals[RT_MAX_GLOBAL] = {0, 0, 0, 0, 0, 0, 0, 0};
   int n_global = 0;
-  if (ctx->global_prims && boxes.size() >= 32) {
+  // tiny scenes (the Cornell boxes: 8 primitives): no tree, every ray tests every primitive, uniformly across the wave
+  const bool tiny = ctx->global_prims && !boxes.empty() && boxes.size() <= RT_MAX_GLOBAL;
+  if (tiny) {
+    for (size_t i = 0; i < boxes.size(); i++) globals[n_global++] = (int32_t)i;
+  } else if (ctx->global_prims && boxes.size() >= 32) {
     rtb::Box all = boxes[0];
     for (const rtb::Box& b : boxes)
       for (int a = 0; a < 3; a++) { all.lo[a] = std::min(all.lo[a], b.lo[a]); all.hi[a] = std::max(all.hi[a], b.hi[a]); }
@@ -1504,22 +1512,23 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
         globals[n_global++] = (int32_t)i;
   }
   std::vector<rtb::Box> tree_boxes;
-  if (n_global) {
+  if (n_global && !tiny) {
     for (size_t i = 0; i < boxes.size(); i++)
       if (!(n_global > 0 && (int32_t)i == globals[0]) && !(n_global > 1 && (int32_t)i == globals[1])) {
         in_tree.push_back((int32_t)i);
         tree_boxes.push_back(boxes[i]);
       }
   }
-  rtb::BuildResult bvh = rtb::build_bvh(n_global ? tree_boxes : boxes, RT_STACK_DEPTH);
-  if (n_global) {  // leaf references back to positions in the primitive tables
+  // (a tiny scene keeps its tree in memory — probe forms and sizes are unchanged — but no render or probe walks it)
+  rtb::BuildResult bvh = rtb::build_bvh(n_global && !tiny ? tree_boxes : boxes, RT_STACK_DEPTH);
+  if (n_global && !tiny) {  // leaf references back to positions in the primitive tables
     auto fix = [&in_tree](int32_t& ref) { if (ref < 0 && ref != rtb::EMPTY_CHILD) ref = ~in_tree[(size_t)~ref]; };
     for (rtb::FlatNode& nd : bvh.nodes) { fix(nd.left); fix(nd.right); }
     fix(bvh.root);
   }
   sc->view.n_global = n_global;
-  sc->view.global_prim[0] = globals[0];
-  sc->view.global_prim[1] = globals[1];
+  sc->view.tree_empty = tiny ? 1 : 0;
+  for (int k = 0; k < RT_MAX_GLOBAL; k++) sc->view.global_prim[k] = globals[k];
   sc->bvh_depth = bvh.depth;
   if (getenv("RT_VERBOSE"))
     fprintf(stderr, "[rt] scene: %zu prims, %zu nodes, BVH depth %d\n", boxes.size(), bvh.nodes.size(), bvh.depth);
@@ -2055,7 +2064,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
-  fp.kb = (uint32_t)ctx->fused_kb; fp.kn = (uint32_t)ctx->fused_kn; fp.kr = use_resume(ctx, scene) ? (uint32_t)ctx->fused_kr : 1u;
+  fp.kb = (uint32_t)ctx->fused_kb; fp.kn = (uint32_t)ctx->fused_kn; fp.kr = use_resume(ctx, scene) ? (uint32_t)ctx->fused_kr : (uint32_t)ctx->fused_kr_sync;
   const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
   const uint32_t tex_only = scene->features & RT_F_TEX_ANY;  // texture kinds present (kernels are specialised on them)
   const bool small_ids = (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768 && scene->view.n_prims < 32000;  // int16 stack entries
@@ -2181,7 +2190,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     else if (!(tex_only & RT_F_TEX_IMAGE)) rc = launch_variant<RT_F_TEX_CHECKER | RT_F_TEX_NOISE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
     else rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
   } else if (!scene->spheres_only && ctx->fused_lds && small_ids && lds_generic_1024 <= 160 * 1024) {
-    if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
+    if (tex_only == 0 && ctx->fused_stats) {  // instrumented build of the Cornell instance (both schedules)
+      if (use_resume(ctx, scene)) rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t, true, true>(ctx, scene, dc, fp, lds_generic_1024, st);
+      else rc = launch_fused<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t, true, false>(ctx, scene, dc, fp, lds_generic_1024, st);
+    } else if (tex_only == 0) rc = launch_variant<RT_F_QUAD | RT_F_MEDIUM, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
     else rc = launch_variant<RT_F_ALL, KIND_GENERIC_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_generic_1024, st);
   } else {
     // HBM-resident scene: four-wide tree by default (fused_wide = 0: the binary tree, kept as a cross-check)

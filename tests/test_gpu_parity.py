@@ -250,6 +250,23 @@ def test_global_primitives_outside_the_tree_change_nothing(ctx):
         assert np.array_equal(a["object_id"], b["object_id"]) and np.array_equal(a["t"], b["t"])
     assert (got[1][0][0]["object_id"] == 0).sum() > 1000  # the ground (object 0) is hit, through the up-front test
     assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2]) and got[0][3] == got[1][3]
+    # scenes of at most eight primitives have no tree at all with the option on: every ray tests every primitive
+    box = ra.Scene("cornell_box", 120, 1.0, "uniform", 16, 12)
+    o2 = OracleScene("cornell_box", 120, 1.0, "uniform", 1, 12)
+    rays2 = o2.primary_rays(time=0.5)
+    cam2 = box.camera_copy()
+    out = {}
+    for on in (0, 1):
+        ctx.set_option("global_prims", on)
+        try:
+            dev = box.upload(ctx)
+        finally:
+            ctx.set_option("global_prims", 1)
+        out[on] = ([probe(ctx, dev, rays2, form) for form in (0, 3)], dev.render_sums(cam2, seed=4), ctx.stats()["rays"])
+        dev.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a["object_id"], b["object_id"]) and np.array_equal(a["t"], b["t"])
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2] and out[1][1].sum() > 0
 
 
 def test_tile_order_feedback_keeps_the_frame(ctx):
