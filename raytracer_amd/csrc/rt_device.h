@@ -176,6 +176,10 @@ __device__ __forceinline__ f3 normalize(f3 a) {
 // |o|*2^-24*|inv| is covered by widening o*inv per axis (nx.. for entry planes, fx.. for exit planes); the box
 // coordinates' own rounding is covered by padding at build time (rt_bvh.cpp).
 #define RT_SLAB_WIDEN 1.0000019f  // exit distances are widened by 16 ulp (+1e-30) before the entry <= exit test
+// f32 upper bound of the best hit distance, widened like the exits: >= t * RT_SLAB_WIDEN + 1e-30 for every t >= 0.  Two
+// more ulp in the factor cover the round-to-nearest conversion and the multiply (a software round-up conversion cost
+// ~15 instructions per accepted hit and per round); a looser bound only culls a little later.
+__device__ __forceinline__ float widen_tmax(double t) { return __builtin_fmaf((float)t, 1.0000021f, 1e-30f); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SlabRay {
   // Per axis two register PAIRS, laid out for v_pk_fma_f32 (two f32 FMAs per issue slot — the packed form is what the
@@ -729,7 +733,7 @@ __device__ __forceinline__ void prim_test(const Acc& acc, TravState& ts, int32_t
   if (h) {
     ts.best_t = t;
     ts.best_prim = pi;
-    ts.tmax_w = __double2float_ru(t) * RT_SLAB_WIDEN + 1e-30f;
+    ts.tmax_w = widen_tmax(t);
   }
 }
 // precondition: ts.cur < 0 && ts.cur != TravDone<StackT>::v

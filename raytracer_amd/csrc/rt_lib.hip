@@ -737,7 +737,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       if (fresh_lane) { t_cur = sc.tree_empty ? kDone : acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); my_rays++; }
       fresh_lane = false;
       ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
-      ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
+      ts.tmax_w = widen_tmax(t_best_t);
       if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, F, o, d, time, RT_TMIN, rng);  // the ground: all starting lanes at once
       // ---- traverse until fewer than kb lanes are unfinished (stragglers keep their progress and go on next round
       //      beside the re-launched lanes); when nothing new was launched, run to completion
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
     if (fresh_lane) { t_cur = sc.tree_empty ? kDone : acc.root(sc.root); t_sp = stack_addr; t_top = kDone; t_best_prim = -1; t_best_t = __builtin_inf(); }
     fresh_lane = false;
     ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
-    ts.tmax_w = __double2float_ru(t_best_t) * RT_SLAB_WIDEN + 1e-30f;
+    ts.tmax_w = widen_tmax(t_best_t);
     if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, features, o, d, time, RT_TMIN, rng);
     traverse_resume<typename AccOf<KIND>::type, StackT, true>(acc, ts, active, features, o, d, time, RT_TMIN, stack, BLOCK, &tc,
                                                               rng, fresh ? kb : 1u, kn);
