@@ -85,7 +85,7 @@ struct Scene {
   // Scenes of at most eight primitives (the Cornell boxes) have no tree at all: every ray tests every primitive in turn,
   // all lanes the same one — no node steps, no divergent leaf rounds (tree_empty).
   int32_t n_global, tree_empty;
-  int32_t global_prim[8];
+  const int32_t* global_list;  // n_global primitive indices (device memory; read with scalar loads)
 };
 
 struct Camera {
@@ -748,24 +748,17 @@ __device__ __forceinline__ void leaf_step(const Acc& acc, TravState& ts, uint32_
 struct GlobalPrims {
   int32_t n;           // primitives tested up-front, outside the tree
   int32_t tree_empty;  // ... and they are ALL the scene's primitives (tiny scenes: no tree at all)
-  int32_t prim[RT_MAX_GLOBAL];
+  const int32_t* list;
 };
-__device__ __forceinline__ GlobalPrims global_prims(const Scene& sc) {
-  GlobalPrims g;
-  g.n = sc.n_global;
-  g.tree_empty = sc.tree_empty;
-#pragma unroll
-  for (int k = 0; k < RT_MAX_GLOBAL; k++) g.prim[k] = sc.global_prim[k];
-  return g;
-}
+__device__ __forceinline__ GlobalPrims global_prims(const Scene& sc) { return {sc.n_global, sc.tree_empty, sc.global_list}; }
 // precondition: ts holds a fresh traversal (trav_restart) and the ray's constants.  The primitive index is the same in
-// every lane, so the type dispatch inside prim_test does not diverge.
+// every lane (a scalar load), so the type dispatch inside prim_test does not diverge.
 template <class Acc>
 __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPrims& gp, TravState& ts, uint32_t features, d3 o,
                                                   d3 d, double time, double tmin, PathRng& rng) {
-#pragma unroll
-  for (int g = 0; g < RT_MAX_GLOBAL; g++)
-    if (g < gp.n) prim_test(acc, ts, gp.prim[g], features, o, d, time, tmin, rng);
+  // (a loop, not eight copies of the test: the list's length is a run-time value and the code stays in the instruction cache)
+#pragma unroll 1
+  for (int g = 0; g < gp.n; g++) prim_test(acc, ts, gp.list[g], features, o, d, time, tmin, rng);
 }
 
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
@@ -776,7 +769,7 @@ __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPr
 template <class Acc, class StackT, bool COUNT>
 __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32_t features, d3 o, d3 d, double time,
                                             double tmin, StackT* stack, int stride, TravCounters* cnt, PathRng& rng,
-                                            GlobalPrims gp = GlobalPrims{0, 0, {0, 0, 0, 0, 0, 0, 0, 0}}) {
+                                            GlobalPrims gp = GlobalPrims{0, 0, nullptr}) {
   constexpr int32_t kDone = TravDone<StackT>::v;
   TravState ts;
   trav_init(ts, root, kDone, lds_addr(stack), o, d);

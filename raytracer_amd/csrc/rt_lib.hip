@@ -1015,6 +1015,7 @@ struct rt_scene {
   BvhNode* d_nodes = nullptr;
   float4* d_nodes4 = nullptr;  // four-wide form of the tree (HBM-resident fused instances)
   uint4* d_nodes4h = nullptr;  // ... with binary16 planes
+  int32_t* d_global = nullptr; // Scene::global_list
   bool half_ok = false;        // every finite plane is inside the binary16 range
   int wide_stack = 0;          // stack entries a traversal of it needs
   Prim* d_prims = nullptr;
@@ -1376,6 +1377,7 @@ int rt_scene_free(rt_ctx* ctx, rt_scene* s) {
   if (s->d_nodes) (void)hipFree(s->d_nodes);
   if (s->d_nodes4) (void)hipFree(s->d_nodes4);
   if (s->d_nodes4h) (void)hipFree(s->d_nodes4h);
+  if (s->d_global) (void)hipFree(s->d_global);
   if (s->d_prims) (void)hipFree(s->d_prims);
   if (s->d_mats) (void)hipFree(s->d_mats);
   if (s->d_texs) (void)hipFree(s->d_texs);
@@ -1528,7 +1530,9 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   }
   sc->view.n_global = n_global;
   sc->view.tree_empty = tiny ? 1 : 0;
-  for (int k = 0; k < RT_MAX_GLOBAL; k++) sc->view.global_prim[k] = globals[k];
+  HIP_TRY(ctx, hipMalloc(&sc->d_global, RT_MAX_GLOBAL * sizeof(int32_t)));
+  HIP_TRY(ctx, hipMemcpy(sc->d_global, globals, RT_MAX_GLOBAL * sizeof(int32_t), hipMemcpyHostToDevice));
+  sc->view.global_list = sc->d_global;
   sc->bvh_depth = bvh.depth;
   if (getenv("RT_VERBOSE"))
     fprintf(stderr, "[rt] scene: %zu prims, %zu nodes, BVH depth %d\n", boxes.size(), bvh.nodes.size(), bvh.depth);
