@@ -1059,7 +1059,7 @@ struct rt_ctx {
   int fused_kr = 16;
   std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
   std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
-  int fused_partner_min = 48;  // partner workgroups only for frames of at least this many Mi samples (C2 split 1 / 2 / 4 / 8 ways:
+  int fused_partner_min = 32;  // partner workgroups only for frames of at least this many Mi samples (C2 split 1 / 2 / 4 / 8 ways:
                                // 9.62 / 5.25 / 3.01 / 1.76 ms with them, 10.13 / 5.29 / 2.96 / 1.67 without)
   int fused_slots = 0;  // tile slots per workgroup (0 = auto)
   int fused_tail4 = 50, fused_tail2 = 30;  // share of the frame's rows (per mille) tiled 4x4 / 2x2 at the end of the tile list
