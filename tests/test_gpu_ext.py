@@ -176,6 +176,32 @@ def test_hbm_resident_tree_forms_agree_on_ext_scenes(ctx, name):
             assert np.sqrt(np.mean((a - f) ** 2)) < 1.2 * noise  # no further apart than two independent seeds
 
 
+@pytest.mark.parametrize("name", ["final_scene_small", "final_scene", "cornell_smoke"])
+def test_global_primitives_with_media_estimate_the_same_image(ctx, name):
+    """Option global_prims on scenes with constant media: the final scenes' enclosing haze sphere leaves the tree and is
+    tested first, Cornell smoke (eight primitives) has no tree at all.  A medium's boundary test draws from the path's
+    random stream, and the order of the tests changes — so the frames are two estimates of the same image, no further
+    apart than two seeds of one configuration, with the same total energy."""
+    from golden_data import load_earth_rgba
+    tex = load_earth_rgba() if name.startswith("final") else None
+    g = ra.Scene(name, 128, 1.0, "uniform", 64, 30, texels=tex)
+    cam = g.camera_copy()
+    frames = {}
+    for on in (1, 0):
+        ctx.set_option("global_prims", on)
+        try:
+            dev = g.upload(ctx)
+        finally:
+            ctx.set_option("global_prims", 1)
+        frames[on] = [dev.render_sums(cam, seed=s).astype(np.float64) for s in ((9, 10) if on else (9,))]
+        dev.close()
+    a, a2 = frames[1]
+    b = frames[0][0]
+    noise = np.sqrt(np.mean((a - a2) ** 2))
+    assert abs(b.sum() - a.sum()) < 5e-3 * a.sum()
+    assert np.sqrt(np.mean((a - b) ** 2)) < 1.2 * noise
+
+
 @pytest.mark.parametrize("name,width", [("book_cover", 300), ("cornell_box", 200), ("final_scene", 240)])
 def test_every_tree_form_returns_the_same_hits(ctx, name, width):
     """rt_intersect over the binary tree is held against the oracle above; here the four-wide trees (f32 and binary16
