@@ -22,8 +22,13 @@ The JSON line also carries
                 flops that run in f64, and — from the committed PMC profile of the same command — the EXECUTED figure
                 (VALU lane-operations per second against the lane peak)
   cpu_baseline  the CPU oracle (C++ restatement of the reference) timed on this host on a bounded sample
-  workloads     (N = 1) the north_star's target workload C5 (Next Week final scene, 4K) and C4 (Cornell smoke): the
-                same measurements + their own CPU legs and GPU / CPU ratios
+  workloads     (N = 1) every other BASELINE config — C1, C3a (earth), C3b (noise), C4 (Cornell smoke), C5 (Next Week
+                final scene, 4K: north_star's target workload) — with the same measurements, its own roofline block and
+                a bounded CPU leg each; and `c5_full`: BASELINE config 5 at its stated size, 3840 x 2160 x 10 000 spp,
+                rendered once as 10 launches of 1000 sample indices each (residue classes mod 10, summed on the device)
+  first_frame_ms  the first rt_render_device call of the process (cold: lazy code-object load, LDS opt-in, occupancy
+                query, no tile-order feedback) next to the steady-state `ms_per_step`; `ms_per_step_feedback_off` is the
+                steady state without the tile order learned from the previous frame of the same view
   strong_workloads  (every N) the configs BASELINE quotes "at 1/2/4/8 GPUs" — Cornell smoke at 1024 spp, a 256-spp slice
                 of the final scene at 4K — split N ways like the headline frame
 """
@@ -52,20 +57,23 @@ WORKLOADS = {
     # BASELINE configs[3] / [4], the ones quoted "at 1/2/4/8 GPUs": split N ways like the headline frame (every N line)
     "c4_1024spp": ("cornell_smoke", 1920, "uniform", 1024, 50, "workload_c4.json", 1024),
     "c5_256spp": ("final_scene", 3840, "uniform", 256, 50, "workload_c5.json", 10000),
+    # BASELINE configs[4] at its stated size: 100 x 100 grid = 10 000 spp at 4K (one step = 10 launches of 1000 spp)
+    "c5_full": ("final_scene", 3840, "uniform", 10000, 50, "workload_c5.json", 10000),
 }
+C5_FULL_PASSES = 10
 # integer work the flop count leaves out (reported separately): the noise texture's lattice hash
 NOISE_INT_OPS_REFERENCE = 8 * (128 * 8 + 64)   # texture.rs:148-162 as written: 8 corners x (128 xoroshiro steps + jump XORs)
 NOISE_INT_OPS_GPU = 40 * 6 + 8 * 12            # 40 GF(2) table lookups (load + 4 xor each) + 8 x (add, convert)
 
 
-def cpu_baseline(scene, width, depth, texels=None, cspp=None):
+def cpu_baseline(scene, width, depth, texels=None, cspp=None, sampler="uniform"):
     """Oracle (kind 'port') on a bounded sample of the same workload (about 10-20 s of wall time on 16 threads):
     the same frame at the config's own 100 spp for C2 (width 1200), 16 spp for the 1920-wide frames, 1 spp at 4K."""
     from oracle_lib import OracleScene
     threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share is 16
     if cspp is None:
         cspp = 100 if width <= 1200 else (16 if width <= 1920 else 1)
-    sc = OracleScene(scene, width, 16.0 / 9.0, "uniform", cspp, depth, texels=texels)
+    sc = OracleScene(scene, width, 16.0 / 9.0, sampler, cspp, depth, texels=texels)
     r = sc.render(threads=threads)
     n = sc.width * sc.height * cspp
     # 1-thread figure on a sub-window (the reference's Arc refcount contention makes it scale sub-linearly)
@@ -74,7 +82,7 @@ def cpu_baseline(scene, width, depth, texels=None, cspp=None):
     n1 = min(32, sc.height - win[1]) * sc.width * cspp
     return {
         "value": n / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": f"{scene} {sc.width}x{sc.height}, uniform {cspp} spp, depth {depth}: {n} samples, "
+        "sample": f"{scene} {sc.width}x{sc.height}, {sampler} {cspp} spp, depth {depth}: {n} samples, "
                   f"{r['seconds']:.2f} s",
         "one_thread_value": n1 / r1["seconds"] / 1e6,
         "one_thread_sample": f"rows {win[1]}..{win[1] + 32}, {n1} samples, {r1['seconds']:.2f} s",
@@ -100,7 +108,46 @@ def load_pmc(workload):
     return None, None
 
 
-def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats):
+def own_tree_flops(wl, own):
+    """Algorithmic flops per sample counted on the tree THIS kernel walks (VERDICT r2 #3a): the per-operation constants
+    of SURVEY §8(d) applied to the box tests, primitive tests by type and rays the instrumented build of the same kernel
+    instance executed (rt_stats.dbg_counts; primitives kept outside the tree included), plus the terms that do not depend
+    on the tree (camera ray, hit record, scatter, textures, sky), which are the fixture's.  The reference-topology figure
+    (`algorithmic_flops_per_sample`) counts 6-quad box lists and a median-split tree the GPU never walks."""
+    p, F = wl["per_sample"], wl["flop_constants"]
+    sph = own["sphere_tests"] + own["moving_tests"]
+    tree = (F["ray"] * own["rays"] + F["box"] * own["box_tests"] + F["sph"] * sph + F["mov"] * own["moving_tests"] +
+            F["sph_root"] * min(p["sphere_disc_pos"], sph) + F["quad"] * own["quad_tests"] + F["medium"] * own["medium_tests"])
+    shared = (F["cam"] + F["hit"] * p["bounce_hits"] + F["lam"] * p["scat_lambert"] + F["met"] * p["scat_metal"] +
+              F["die"] * p["scat_dielectric"] + F["iso"] * p["scat_isotropic"] + F["tex_chk"] * p["tex_checker"] +
+              F["tex_img"] * p["tex_image"] + F["tex_noise"] * p["tex_noise"] + F["mul"] * p["bounce_hits"] + F["sky"] * p["misses"])
+    return tree + shared
+
+
+def measure_own_tree(ctx, rig, stream, d_ptr, spp_slice=None):
+    """One frame through the instrumented build of the production instance (not timed): operation counts per sample."""
+    ctx.set_option("fused_stats", 1)
+    try:
+        kw = {}
+        if spp_slice:  # a residue class of the sample indices is enough for per-sample averages
+            kw = dict(sample_begin=0, sample_stride=spp_slice)
+        rig.dev.render_device(rig.cam, d_ptr, seed=0x1234, stream=stream, **kw)
+        import torch
+        torch.cuda.synchronize()
+        st = ctx.stats()
+    finally:
+        ctx.set_option("fused_stats", 0)
+    n = max(st["paths"], 1)
+    c = st["dbg_counts"]
+    if c[0] == 0 and c[1] + c[2] + c[3] + c[4] == 0:
+        return None  # this instance has no instrumented build
+    return {"rays": st["rays"] / n, "box_tests": c[0] / n, "sphere_tests": c[1] / n, "moving_tests": c[2] / n,
+            "quad_tests": c[3] / n, "medium_tests": c[4] / n,
+            "node_loop_lane_slots": {"walking": st["dbg"][0], "at_leaf": c[5],
+                                     "finished": c[6], "no_path": c[7]}}
+
+
+def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats, own=None, frame_samples=None):
     fps = wl["flops_per_sample"]
     achieved = samples_per_launch * fps / (kernel_ms * 1e-3) / 1e12
     share = f64_share(wl)
@@ -118,7 +165,27 @@ def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats):
             "reference_int_ops_per_lookup": NOISE_INT_OPS_REFERENCE, "gpu_int_ops_per_lookup": NOISE_INT_OPS_GPU,
             "reference_int_ops_per_sample": wl["per_sample"]["tex_noise"] * NOISE_INT_OPS_REFERENCE,
             "gpu_int_ops_per_sample": wl["per_sample"]["tex_noise"] * NOISE_INT_OPS_GPU}
+    if own:
+        fo = own_tree_flops(wl, own)
+        ach = samples_per_launch * fo / (kernel_ms * 1e-3) / 1e12
+        slots = own.pop("node_loop_lane_slots", None)
+        out["own_tree"] = {"flops_per_sample": fo, "achieved": ach, "frac_own_tree": ach / VALU_FP32_PEAK_TFLOPS,
+                           "per_sample": own,
+                           "note": "the same constants applied to what the instrumented build of this kernel instance executes on "
+                                   "the library's own tree (binned-SAH, huge primitives outside the tree); tree-independent terms "
+                                   "from the fixture"}
+        out["frac_own_tree"] = ach / VALU_FP32_PEAK_TFLOPS
+        if slots and sum(slots.values()) > 0:
+            tot = float(sum(slots.values()))
+            out["own_tree"]["node_loop_lane_share"] = {k: v / tot for k, v in slots.items()}
+    if out["frac_of_mixed_peak"] > 1.0:
+        out["note_frac"] = ("frac_of_mixed_peak > 1: the kernel does NOT execute the counted work — `achieved` prices the "
+                            "reference algorithm on the reference-topology tree (6-quad box lists, median splits), which "
+                            "needs far more primitive and box tests than the library's tree; `frac` is therefore not a "
+                            "measure of this kernel's efficiency — use `frac_own_tree` and `executed`")
     pmc, src = load_pmc(workload)
+    # the committed PMC counts are those of the WHOLE frame: scale them to the samples this launch rendered
+    scale = (samples_per_launch / frame_samples) if frame_samples else 1.0
     if pmc:
         der, cnt = pmc.get("derived", {}), pmc.get("counters", {})
         if "hbm_write_bytes" in der and "hbm_fetch_bytes_x2_upper" in der:
@@ -126,9 +193,10 @@ def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats):
             out["traffic_note"] = ("HBM bytes per launch (rocprofv3 FETCH_SIZE x2 upper bound + WRITE_SIZE, " + src +
                                    "); algorithmic output is W*H*12 B; scene and path state live in LDS / L2 / registers")
         if "SQ_INSTS_VALU" in cnt and der.get("valu_active_lane_fraction"):
-            lane_ops = cnt["SQ_INSTS_VALU"] * 64 * der["valu_active_lane_fraction"]
+            lane_ops = cnt["SQ_INSTS_VALU"] * scale * 64 * der["valu_active_lane_fraction"]
             out["executed"] = {
-                "valu_wave_instructions_per_launch": cnt["SQ_INSTS_VALU"],
+                "valu_wave_instructions_per_launch": cnt["SQ_INSTS_VALU"] * scale,
+                "scaled_to_share_of_frame": scale,
                 "valu_active_lane_fraction": der["valu_active_lane_fraction"],
                 "lane_ops_per_s_tera": lane_ops / (kernel_ms * 1e-3) / 1e12, "lane_peak_tera": VALU_LANE_PEAK_TOPS,
                 "lane_utilisation": lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_LANE_PEAK_TOPS,
@@ -173,7 +241,8 @@ def main():
     ap.add_argument("--no-strong-workloads", action="store_true",
                     help="skip the split-frame runs of the multi-GPU configs C4 (1024 spp) and C5 (256-spp slice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-workloads", action="store_true", help="skip the C5 / C4 block of the N = 1 line")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the block of the other BASELINE configs on the N = 1 line")
+    ap.add_argument("--no-c5-full", action="store_true", help="skip BASELINE config 5 at its full 10 000 spp (about half a minute)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="rt_set_option override (profiling runs: fused_partner=0, rocprofv3 serialises kernels)")
     ap.add_argument("--rehearse", action="store_true",
@@ -221,6 +290,13 @@ def main():
     stream = side.cuda_stream
     d_sum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     d_u8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    # the process's FIRST frame (the reference renders one frame per process): nothing primed, nothing cached
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b0, e0, s0 = mg.sample_slice(rank, world, rig.spp)
+    rig.dev.render_device(rig.cam, d_sum.data_ptr(), seed=seed0 ^ 0x5555, sample_begin=b0, sample_end=e0, sample_stride=s0, stream=stream)
+    torch.cuda.synchronize()
+    first_frame_ms = (time.perf_counter() - t0) * 1e3
 
     def reduce_to_rank0():
         if world > 1 and args.rehearse:
@@ -282,7 +358,18 @@ def main():
     k_ms = sorted(kernel_ms)[len(kernel_ms) // 2]
     my_samples = stats["paths"]
 
-    extra = {}
+    extra = {"first_frame_ms": first_frame_ms,
+             "first_frame_note": "wall time of the first rt_render_device call of this process on this rank (cold: code-object "
+                                 "load, LDS opt-in, occupancy query, tile order unprimed), scene already uploaded"}
+    own = None
+    if rank == 0:
+        own = measure_own_tree(ctx, rig, stream, d_sum.data_ptr())
+    if world == 1 and args.workload in ("c1", "c2", "c4"):
+        # steady state without the tile order learned from the previous frame of the same view
+        ctx.set_option("fused_feedback", 0)
+        el_off = timed(step_strong, max(3, min(args.steps, 10)), 1)
+        ctx.set_option("fused_feedback", 1)
+        extra["ms_per_step_feedback_off"] = el_off / max(3, min(args.steps, 10)) * 1e3
     if world > 1:
         # (1) the N-rank frame is the one-rank frame: rank 0 renders the whole frame itself and compares
         step_strong(12345)
@@ -355,7 +442,7 @@ def main():
                        "spp_per_gpu": [mg.samples_in_slice(*mg.sample_slice(r, world, rig.spp)) for r in range(world)],
                        "parallelism": (f"sample indices split x{world} (residue classes) + one RCCL reduce of "
                                        f"{W * H * 12} B per rank") if world > 1 else "single GPU"},
-            "roofline": roofline_block(args.workload, rig.wl, my_samples, k_ms, stats),
+            "roofline": roofline_block(args.workload, rig.wl, my_samples, k_ms, stats, own, frame_samples),
         }
         out["roofline"]["note"] = ("rank 0's launch: %d of the frame's %d samples" % (my_samples, frame_samples)) if world > 1 else \
             "one launch = the whole frame"
@@ -364,29 +451,71 @@ def main():
             out["cpu_baseline"] = cpu_baseline(rig.scene_name, rig.width_req, rig.depth, rig.texels)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if world == 1 and args.workload == "c2" and not args.no_workloads:
-            # the north_star's target workload (C5) and the emissive / volume workload (C4), with their own CPU legs
+            # every other BASELINE config, each with its own roofline block and a bounded CPU leg (C5 = the north_star's
+            # target workload).  CPU samples: C1 in full; 16 / 4 spp of the 1080p frames; 1 spp at 4K.
             out["workloads"] = {}
-            for w, csp in (("c5", 1), ("c4", 4)):
+            for w, csp in (("c1", 10), ("c3a", 16), ("c3b", 4), ("c4", 4), ("c5", 1)):
                 r2 = Rig(ra, ctx, w)
                 d2 = torch.zeros((r2.H, r2.W, 3), dtype=torch.float32, device="cuda")
-                for i in range(2):
-                    r2.dev.render_device(r2.cam, d2.data_ptr(), seed=seed0 + i, stream=stream)
                 torch.cuda.synchronize()
-                n2 = 3
+                t0 = time.perf_counter()
+                r2.dev.render_device(r2.cam, d2.data_ptr(), seed=seed0, stream=stream)
+                torch.cuda.synchronize()
+                first2 = (time.perf_counter() - t0) * 1e3
+                r2.dev.render_device(r2.cam, d2.data_ptr(), seed=seed0 + 1, stream=stream)
+                torch.cuda.synchronize()
+                n2 = 3 if r2.W * r2.H * r2.spp > (1 << 26) else 20
                 t0 = time.perf_counter()
                 for i in range(n2):
                     r2.dev.render_device(r2.cam, d2.data_ptr(), seed=seed0 + 2 + i, stream=stream)
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / n2 * 1e3
                 st2 = ctx.stats()
+                own2 = measure_own_tree(ctx, r2, stream, d2.data_ptr(), spp_slice=16 if r2.spp >= 256 else None)
                 entry = {"workload": r2.label(), "value": r2.W * r2.H * r2.spp / ms / 1e3, "unit": "Msamples/s",
-                         "ms_per_step": ms, "steps": n2,
-                         "roofline": roofline_block(w, r2.wl, st2["paths"], st2["ms_total"], st2)}
+                         "ms_per_step": ms, "steps": n2, "first_frame_ms": first2, "config_spp": r2.config_spp, "spp": r2.spp,
+                         "roofline": roofline_block(w, r2.wl, st2["paths"], st2["ms_total"], st2, own2)}
                 if not args.no_cpu_baseline:
-                    entry["cpu_baseline"] = cpu_baseline(r2.scene_name, r2.width_req, r2.depth, r2.texels, cspp=csp)
+                    entry["cpu_baseline"] = cpu_baseline(r2.scene_name, r2.width_req, r2.depth, r2.texels, cspp=csp, sampler=r2.sampler)
                     entry["gpu_over_cpu"] = entry["value"] / entry["cpu_baseline"]["value"]
                 out["workloads"][w] = entry
                 del d2, r2
+            if not args.no_c5_full:
+                # BASELINE configs[4] at its stated size on ONE GPU: 3840 x 2160 x 10 000 spp = 82 944 M samples, as 10
+                # launches of 1000 sample indices each (residue classes mod 10 of the 100 x 100 grid: the checkpointable
+                # form, Camera::render_progressive's), partial sums added on the device.
+                r5 = Rig(ra, ctx, "c5_full")
+                acc5 = torch.zeros((r5.H, r5.W, 3), dtype=torch.float32, device="cuda")
+                p5 = torch.zeros_like(acc5)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k_ms5, rays5 = 0.0, 0
+                for ps in range(C5_FULL_PASSES):
+                    r5.dev.render_device(r5.cam, p5.data_ptr(), seed=seed0, sample_begin=ps, sample_stride=C5_FULL_PASSES, stream=stream)
+                    acc5 += p5
+                    torch.cuda.synchronize()  # (also: a progress point every ~3 s)
+                    st5 = ctx.stats()         # raises if a frame was cut short (watchdog)
+                    k_ms5 += st5["ms_total"]
+                    rays5 += st5["rays"]
+                    assert st5["samples_nan"] == 0 and st5["samples_clamped"] == 0
+                el5 = time.perf_counter() - t0
+                n5 = r5.W * r5.H * r5.spp
+                mean5 = float(acc5.mean().item()) / r5.spp
+                # the 16-spp frame of the `c5` entry estimates the same image: means agree to Monte-Carlo noise
+                r16 = Rig(ra, ctx, "c5")
+                d16 = torch.zeros((r16.H, r16.W, 3), dtype=torch.float32, device="cuda")
+                r16.dev.render_device(r16.cam, d16.data_ptr(), seed=seed0 + 77, stream=stream)
+                torch.cuda.synchronize()
+                mean16 = float(d16.mean().item()) / r16.spp
+                assert abs(mean5 - mean16) <= 0.01 * abs(mean5), (mean5, mean16)
+                out["workloads"]["c5_full"] = {
+                    "workload": r5.label(), "value": n5 / el5 / 1e6, "unit": "Msamples/s", "seconds": el5, "steps": 1,
+                    "launches": C5_FULL_PASSES, "config_spp": r5.config_spp, "spp": r5.spp, "samples": n5, "rays": rays5,
+                    "kernel_ms_total": k_ms5, "mean_linear_radiance": mean5, "mean_linear_radiance_16spp_frame": mean16,
+                    "roofline": roofline_block("c5", r5.wl, n5, k_ms5, {"rays": rays5, "paths": n5}, out["workloads"]["c5"]["roofline"].get("own_tree", {}).get("per_sample"))}
+                if "cpu_baseline" in out["workloads"]["c5"]:
+                    out["workloads"]["c5_full"]["gpu_over_cpu"] = n5 / el5 / 1e6 / out["workloads"]["c5"]["cpu_baseline"]["value"]
+                del acc5, p5, d16, r5, r16
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
-#define RT_NOALLOC_MAX_PIXELS (1u << 24) /* largest frame rt_render_device_noalloc accepts (width * height) */
+#define RT_ABI_VERSION 2 /* 2: rt_stats grew samples_nan / samples_clamped / lib_alloc_calls; rt_render_batch_device */
+#define RT_NOALLOC_MAX_PIXELS (1u << 24) /* largest frame rt_render_device_noalloc accepts (width * height); no buffer imposes it
+                                          * any more (the fixed scratch is 1 KiB of control words): kept for interface stability */
 
 typedef enum rt_status {
   RT_OK = 0,
@@ -157,6 +158,17 @@ typedef struct rt_stats {
   uint64_t intersect_launches;
   uint64_t probe_rays, probe_node_visits, probe_prim_tests; /* rt_intersect traversal counters since rt_init */
   float dbg[16]; /* "fused_stats" diagnostic build: lane-work / wave-trip tallies (nodes, leaves, shade, regen) */
+  /* Samples whose radiance did not reach the frame as computed (fused mode; the reference has no counterpart: its f64
+   * sums carry NaN / inf into the pixel, color.rs:68-73 then quantises NaN to 0): a NaN or negative-zero-or-less radiance
+   * channel adds nothing, a channel above 2^20 is added as 2^20.  Both are zero for every frame of the shipped scenes
+   * (tests/test_gpu_parity.py); a caller that sees them non-zero knows that the frame dropped energy. */
+  uint64_t samples_nan;     /* radiance channels that were NaN (added as 0) */
+  uint64_t samples_clamped; /* radiance channels above 2^20 (added as 2^20) */
+  uint64_t dbg_counts[8];   /* "fused_stats" build, exact: [0] child boxes tested (node steps x 2; x 4 on the four-wide tree), [1..4] primitive tests by type (static sphere,
+                             * moving sphere, quad, medium; tree leaves + primitives kept outside the tree), [5..7] node-loop
+                             * trips a lane sat out waiting at a leaf / finished / without a path */
+  uint64_t lib_alloc_calls; /* hipMalloc / hipFree / stream / event creations this library has made in this process since
+                             * it was loaded (all contexts): unchanged across a call <=> that call allocated nothing */
 } rt_stats;
 
 /* ---- entry points --------------------------------------------------------------------------------------*/
@@ -191,7 +203,14 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
  * Replaces: the body of Camera::render / render_rect / sample_pixel / sample_point / ray_color
  * (src/camera/mod.rs:54-214).  rt_render takes a HOST output pointer (blocking; includes the D2H copy);
  * rt_render_device takes a DEVICE pointer and a hipStream_t (NULL = the ctx's stream) and is asynchronous
- * with respect to the host. */
+ * with respect to the host.
+ * Frame completeness: the persistent kernel's scheduler has a watchdog (a wave that finds no work for ~10 s gives up and
+ * raises a flag instead of hanging the GPU; the tiles it skipped keep whatever `d_out_sum` held).  The blocking entry
+ * points (rt_render, rt_multi_render, rt_multi_render_device) check the flag and return RT_E_INTERNAL for such a frame.
+ * Callers of the asynchronous ones (rt_render_device, rt_render_device_noalloc, rt_render_batch_device) MUST call
+ * rt_get_stats after synchronising to learn whether the frame is complete: it returns RT_E_INTERNAL when the flag is set.
+ * Streams: work of one ctx is ordered through the stream it is issued on; calls on a ctx must not overlap in time on
+ * different streams (tile-order feedback from the previous frame is only used when that frame ran on the same stream). */
 int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
               uint32_t sample_end, uint32_t sample_stride, float* out_sum);
 int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,

@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RT_ABI_VERSION: c_int = 1;
+pub const RT_ABI_VERSION: c_int = 2;
 pub const RT_NOALLOC_MAX_PIXELS: u32 = 1 << 24;
 
 pub const RT_OK: c_int = 0;
@@ -86,6 +86,7 @@ pub struct rt_stats {
     pub ms_total: f32, pub ms_generate: f32, pub ms_intersect: f32, pub ms_shade: f32, pub ms_accumulate: f32,
     pub intersect_launches: u64, pub probe_rays: u64, pub probe_node_visits: u64, pub probe_prim_tests: u64,
     pub dbg: [f32; 16],
+    pub samples_nan: u64, pub samples_clamped: u64, pub dbg_counts: [u64; 8], pub lib_alloc_calls: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]

@@ -9,6 +9,26 @@ use crate::ffi::*;
 use crate::flatten::FlatScene;
 use crate::hittable::Hittable;
 
+/// The process's GPU backend: one rt_ctx (resolve, single-GPU render) and, when RT_GPUS lists several devices, an
+/// rt_multi over them.  Lives until the process ends (the reference renders from one thread for the process's lifetime).
+struct Backend { ctx: *mut rt_ctx, multi: *mut rt_multi }
+unsafe impl Send for Backend {}
+unsafe impl Sync for Backend {}
+static BACKEND: std::sync::OnceLock<Backend> = std::sync::OnceLock::new();
+fn backend() -> &'static Backend {
+    BACKEND.get_or_init(|| unsafe {
+        let gpus: Vec<i32> = std::env::var("RT_GPUS").ok()
+            .map(|s| s.split(',').filter_map(|t| t.trim().parse().ok()).collect()).unwrap_or_default();
+        let mut ctx = std::ptr::null_mut();
+        check(rt_init(*gpus.first().unwrap_or(&0), &mut ctx), std::ptr::null_mut());
+        let mut multi = std::ptr::null_mut();
+        if gpus.len() > 1 {
+            check_multi(rt_multi_init(gpus.as_ptr(), gpus.len() as i32, &mut multi), std::ptr::null_mut());
+        }
+        Backend { ctx, multi }
+    })
+}
+
 impl Camera {
     /// The private fields of mod.rs:26-51 as the library's camera block.
     fn abi_camera(&self) -> rt_camera {
@@ -47,26 +67,24 @@ impl Camera {
         let mut sums = vec![0f32; w * h * 3];
         let mut rgb = vec![0f64; w * h * 3];
         unsafe {
-            // every GPU of the node when RT_GPUS lists several ("0,1,2,3,4,5,6,7"), else one context on GPU 0
-            let gpus: Vec<i32> = std::env::var("RT_GPUS").ok()
-                .map(|s| s.split(',').filter_map(|t| t.trim().parse().ok()).collect()).unwrap_or_default();
-            let mut ctx = std::ptr::null_mut();
-            check(rt_init(*gpus.first().unwrap_or(&0), &mut ctx), std::ptr::null_mut());
-            if gpus.len() > 1 {
-                let mut m = std::ptr::null_mut();
-                check_multi(rt_multi_init(gpus.as_ptr(), gpus.len() as i32, &mut m), std::ptr::null_mut());
-                check_multi(rt_multi_scene_upload(m, &desc), m);
-                check_multi(rt_multi_render(m, &cam, seed, 0, spp as u32, 1, sums.as_mut_ptr()), m);
-                rt_multi_shutdown(m);
+            // One backend per process, created on the first frame and kept (a context owns a stream, events, staging
+            // buffers and per-kernel launch state: creating one per frame would pay that again for every frame of an
+            // animation or a progressive render).  Every GPU of the node when RT_GPUS lists several
+            // ("0,1,2,3,4,5,6,7"), else one context on GPU 0.  Camera::render is called from one dedicated render
+            // thread (main.rs:50-58), which is what the library's "one ctx per calling thread" rule asks for.
+            let be = backend();
+            if !be.multi.is_null() {
+                check_multi(rt_multi_scene_upload(be.multi, &desc), be.multi);
+                check_multi(rt_multi_render(be.multi, &cam, seed, 0, spp as u32, 1, sums.as_mut_ptr()), be.multi);
             } else {
                 let mut scene = std::ptr::null_mut();
-                check(rt_scene_upload(ctx, &desc, &mut scene), ctx);
-                check(rt_render(ctx, scene, &cam, seed, 0, spp as u32, 1, sums.as_mut_ptr()), ctx);
-                rt_scene_free(ctx, scene);
+                check(rt_scene_upload(be.ctx, &desc, &mut scene), be.ctx);
+                // blocking; returns RT_E_INTERNAL (-> panic, the reference's error style) for an incomplete frame
+                check(rt_render(be.ctx, scene, &cam, seed, 0, spp as u32, 1, sums.as_mut_ptr()), be.ctx);
+                rt_scene_free(be.ctx, scene);
             }
             // mean, gamma 2.2 (mod.rs:134, color.rs:58-61): what the tile messages carry
-            check(rt_resolve(ctx, sums.as_ptr(), w as u32, h as u32, spp as u32, 2.2, rgb.as_mut_ptr(), std::ptr::null_mut()), ctx);
-            rt_shutdown(ctx);
+            check(rt_resolve(be.ctx, sums.as_ptr(), w as u32, h as u32, spp as u32, 2.2, rgb.as_mut_ptr(), std::ptr::null_mut()), be.ctx);
         }
         let image_buffer: Vec<Color> = rgb.chunks_exact(3).map(|c| Color::new(c[0], c[1], c[2])).collect();
 

@@ -70,7 +70,8 @@ class RtStats(C.Structure):
                 ("ms_total", C.c_float), ("ms_generate", C.c_float), ("ms_intersect", C.c_float),
                 ("ms_shade", C.c_float), ("ms_accumulate", C.c_float), ("intersect_launches", C.c_uint64),
                 ("probe_rays", C.c_uint64), ("probe_node_visits", C.c_uint64), ("probe_prim_tests", C.c_uint64),
-                ("dbg", C.c_float * 16)]
+                ("dbg", C.c_float * 16), ("samples_nan", C.c_uint64), ("samples_clamped", C.c_uint64), ("dbg_counts", C.c_uint64 * 8),
+                ("lib_alloc_calls", C.c_uint64)]
 
 
 class RtMultiStats(C.Structure):
@@ -220,6 +221,7 @@ class Context:
         self.check(self.L.rt_get_stats(self.h, C.byref(s)))
         d = {f: getattr(s, f) for f, _ in RtStats._fields_}
         d["dbg"] = list(s.dbg)
+        d["dbg_counts"] = list(s.dbg_counts)
         return d
 
     def synchronize(self):

@@ -453,6 +453,7 @@ struct TravCounters {
   uint32_t nodes, prims;  // per-lane node steps / leaf tests
   float wnodes, wprims;   // per-lane share of the wave's loop trips (sums to one per executed trip)
   float t_nodes, t_prims; // per-lane share of the wave's cycles in the inner-node loop / leaf section
+  uint32_t t_sph, t_mov, t_quad, t_med;      // leaf tests by primitive type (static sphere, moving sphere, quad, medium)
   uint32_t idle_leaf, idle_done, idle_free;  // node-loop trips this lane sat out: waiting at a leaf / finished, waiting for shading / without a path
 };
 __device__ __forceinline__ uint64_t now_cycles() { return __builtin_readcyclecounter(); }
@@ -761,6 +762,12 @@ __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPr
   for (int g = 0; g < gp.n; g++) prim_test(acc, ts, gp.list[g], features, o, d, time, tmin, rng);
 }
 
+template <class Acc>
+__device__ __forceinline__ void count_leaf_type(const Acc& acc, int32_t pi, TravCounters* cnt) {
+  const uint32_t ty = acc.type(pi);
+  cnt->t_sph += ty == 0u; cnt->t_mov += ty == 1u; cnt->t_quad += ty == 2u; cnt->t_med += ty >= 3u;
+}
+
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
 // stack (entries `stride` elements apart => bank-conflict free).  "while-while" form: lanes walk inner
 // nodes until they hold a leaf, then the wave runs the (expensive, f64) leaf test together.
@@ -784,7 +791,7 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
     if (ts.cur != kDone) {
-      if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
+      if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); count_leaf_type(acc, ~ts.cur, cnt); }
       leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
     }
@@ -828,7 +835,7 @@ __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, b
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
     if (ts.cur < 0 && ts.cur != kDone) {
-      if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); }
+      if (COUNT) { cnt->prims++; cnt->wprims += wave_share(); count_leaf_type(acc, ~ts.cur, cnt); }
       leaf_step(acc, ts, features, o, d, time, tmin, stack, stride, rng);
       if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_prims += (float)(t1 - t0) * wave_share(); }
     }
@@ -1104,7 +1111,11 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
   f3 att, dir;
   if (kind == 0u) {  // Lambertian (materials.rs:28-43)
     dir = n + u;
-    const float th = 1e-9f;
+    // near_zero (vec3.rs:89-92, threshold 1e-9 on f64 components): the guard exists so that a direction that cancelled
+    // to rounding noise is not sent out.  n and u are unit vectors in f32 here, so the sum's noise floor is ~6e-8 per
+    // component, not 1e-16: a literal 1e-9 could never fire while a ~1e-8-long garbage direction went out.  Scaled to
+    // f32: 16 ulp of 1.0.  (Probability of either event ~1e-13 per bounce: statistically invisible, as in the reference.)
+    const float th = 9.5367431640625e-07f;
     if (__builtin_fabsf(dir.x) < th && __builtin_fabsf(dir.y) < th && __builtin_fabsf(dir.z) < th) dir = n;
     if (M.tex < 0) att = {M.albedo[0], M.albedo[1], M.albedo[2]};
     else att = tex_value<F>(sc, acc, M.tex, hit.prim, h, o, d, time, hit.t);

@@ -22,6 +22,9 @@
 #include "../../include/rt_abi.h"
 #include "rt_bvh.h"
 #include "rt_device.h"
+#include "rt_internal.h"
+
+std::atomic<uint64_t> rti::g_alloc_calls{0};
 
 using namespace rtd;
 
@@ -287,6 +290,12 @@ struct FusedParams {
   // the classes the previous frame of the same scene and camera recorded (deepest first).
   const uint32_t* order;
   unsigned char* depth_out;
+  // Fixed-point format of the tile sums (to_fix / flush_finished): a sample channel is clamped to 2^20 and scaled by
+  // 2^fix_bits, fix_bits = min(40, 43 - ceil(log2 K)), so that the K samples of a pixel cannot overflow the u64 slot
+  // whatever they are (K <= 8: 2^-40 resolution; C2's 100: 2^-36; 10 000: 2^-29; the output is f32).
+  float fix_scale;
+  double fix_inv;
+  uint32_t poll_limit;  // watchdog: polls of the "nothing to hand out" loop before a wave gives up (2^24; option dbg_watchdog_polls)
   unsigned long long* timeline;  // instrumented build: [0] earliest wave start, [1] latest wave end, [2] sum of wave ends, [3] sum of the times waves found the tile list used up (wall_clock64 ticks, low 40 bits in the sums)
 };
 #define RT_TILE_MASK 0x03FFFFFFu  // WgSched::tile: low 26 bits = tile, bits 26..28 = depth-class flags of its paths so far
@@ -305,7 +314,7 @@ static_assert(sizeof(WgSched) % 16 == 0, "scheduler block keeps the LDS regions 
 #define RT_CUR_NONE 0xFFFFFFFEu
 #define RT_CUR_OPENING 0xFFFFFFFDu
 #define RT_CUR_EXHAUSTED 0xFFFFFFFFu
-#define RT_FIX_SCALE 1099511627776.0f  // 2^40
+#define RT_FIX_CLAMP 1048576.0f  // 2^20: largest radiance channel a sample can add
 
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5,
        KIND_GENERIC_WIDE_HALF = 6, KIND_SPHERES_WIDE_HALF = 7 };
@@ -341,10 +350,19 @@ __device__ __forceinline__ void cursor_store(LdsSched* sched, uint32_t hi, uint3
   __hip_atomic_store(&sched->cursor, ((unsigned long long)hi << 32) | lo, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ unsigned long long to_fix(float v) {
-  if (!(v > 0.f)) return 0ull;  // also NaN
-  v = fminf(v, 1048576.0f);
-  return (unsigned long long)(v * RT_FIX_SCALE);
+// Radiance channel -> fixed point.  The two things that make a sample reach the frame differently from what was
+// computed are counted (rt_stats.samples_nan / samples_clamped; `anomalies` = the render's ray counter block: [1] NaN
+// channels, [2] clamped channels): rare by construction, so each is a device atomic on the spot.
+__device__ __forceinline__ unsigned long long to_fix(float v, float scale, unsigned long long* anomalies) {
+  if (!(v > 0.f)) {
+    if (v != v) atomicAdd(anomalies + 1, 1ull);
+    return 0ull;
+  }
+  if (v > RT_FIX_CLAMP) {
+    atomicAdd(anomalies + 2, 1ull);
+    v = RT_FIX_CLAMP;
+  }
+  return (unsigned long long)(v * scale);
 }
 
 __global__ void k_store_camera(Camera cam, Camera* __restrict__ dst) {
@@ -482,7 +500,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   // The camera block (26 doubles) stays in memory: read with scalar loads where a ray is generated instead of
   // occupying ~60 SGPRs for the whole kernel (they spilled to VGPR lanes: 68 v_readlane per regeneration).
   struct { uint32_t width, height, max_depth; } cam = {camp->width, camp->height, camp->max_depth};
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0};
   float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
   uint64_t st_t0 = 0, st_tk = 0;
   float st_twait = 0.f;                  // cycles in the "nothing to hand out" polling loop
@@ -541,7 +559,8 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     if (STATS) st_tshade += (float)(now_cycles() - st_t0) * wave_share();
     bool alive = so.alive;
     if (!alive) {
-      const unsigned long long r = to_fix(so.radiance.x), g = to_fix(so.radiance.y), b = to_fix(so.radiance.z);
+      const unsigned long long r = to_fix(so.radiance.x, fp.fix_scale, ray_total), g = to_fix(so.radiance.y, fp.fix_scale, ray_total),
+                               b = to_fix(so.radiance.z, fp.fix_scale, ray_total);
       if (r) atomicAdd(&l_acc[lpix * 3 + 0], r);
       if (g) atomicAdd(&l_acc[lpix * 3 + 1], g);
       if (b) atomicAdd(&l_acc[lpix * 3 + 2], b);
@@ -578,9 +597,9 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       unsigned long long* a = l_acc + s * 192u + lane * 3u;
       if (lane < (1u << (2u * tsh)) && px < cam.width && py < cam.height) {
         float* q = out_sum + ((size_t)py * cam.width + px) * 3;
-        q[0] = (float)((double)a[0] * 9.094947017729282e-13);  // 2^-40
-        q[1] = (float)((double)a[1] * 9.094947017729282e-13);
-        q[2] = (float)((double)a[2] * 9.094947017729282e-13);
+        q[0] = (float)((double)a[0] * fp.fix_inv);  // 2^-fix_bits
+        q[1] = (float)((double)a[1] * fp.fix_inv);
+        q[2] = (float)((double)a[2] * fp.fix_inv);
       }
       a[0] = 0; a[1] = 0; a[2] = 0;
       if (lane == 0) __hip_atomic_store(&sched->state[s], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -721,7 +740,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
             if (lane == 0) chi = (uint32_t)(__hip_atomic_load(&sp->cursor, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
             go = (uint32_t)__builtin_amdgcn_readfirstlane((int)chi) != RT_CUR_OPENING;
           }
-        } while (!go && ++polls < (1u << 24));
+        } while (!go && ++polls < fp.poll_limit);
         if (STATS) { st_twait += (float)(now_cycles() - st_t0) * (1.0f / 64.0f); }
         if (!go) {
           if (lane == 0) atomicOr(reinterpret_cast<uint32_t*>(tile_counter + 1), 1u);
@@ -783,11 +802,14 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     // longest wave lifetime (positive floats order like their bit patterns): against the mean, the frame's tail
     if (lane == 0) atomicMax(reinterpret_cast<int*>(&dbg[13]), __float_as_int(st_ttotal * 64.0f));
     if (fp.timeline) {  // node-loop trips sat out, by reason
-      unsigned long long v3[3] = {tc.idle_leaf, tc.idle_done, tc.idle_free};
-      for (int k = 0; k < 3; k++) {
-        unsigned long long x = v3[k];
+      // [4..6] node-loop trips sat out by reason, [7] child boxes tested (node steps x 2, or x 4 on the four-wide tree),
+      // [8..11] leaf tests by primitive type (exact counts)
+      constexpr unsigned long long kBoxes = AccOf<KIND>::type::kWide ? 4ull : 2ull;
+      unsigned long long v8[8] = {tc.idle_leaf, tc.idle_done, tc.idle_free, tc.nodes * kBoxes, tc.t_sph, tc.t_mov, tc.t_quad, tc.t_med};
+      for (int k = 0; k < 8; k++) {
+        unsigned long long x = v8[k];
         for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
-        if (lane == 0) atomicAdd(&fp.timeline[4 + k], x);
+        if (lane == 0 && x) atomicAdd(&fp.timeline[4 + k], x);
       }
     }
     if (fp.timeline && lane == 0) {
@@ -875,7 +897,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
   __shared__ uint32_t stack_rows[(RT_STACK_DEPTH + 1) * RT_BLOCK];  // row 0: guard row below the columns (trav_pop)
   uint32_t* const stack = stack_rows + RT_BLOCK;
   const uint32_t stride = gridDim.x * blockDim.x;
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
@@ -932,7 +954,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
   const uint32_t per = (n + n_waves - 1) / n_waves;
   uint32_t next = min(n, wave * per);
   const uint32_t total = min(n, next + per);
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0};
   bool active = false, fresh_lane = false, fresh = false;
   uint32_t ray_index = 0;
   d3 o = {0, 0, 0}, d = {0, 0, 0};
@@ -1027,6 +1049,7 @@ struct rt_scene {
   int bvh_depth = 0;
   uint64_t serial = 0;       // unique per upload (tile-order feedback recognises "the same scene" by it)
   uint32_t features = 0;     // RT_F_* of what the scene contains
+  uint32_t global_types[4] = {0, 0, 0, 0};  // primitives on the global list by type (static sphere, moving sphere, quad, medium)
   bool spheres_only = false;
 };
 
@@ -1043,7 +1066,7 @@ struct WorkBuffers {
 struct FrameScratch {
   unsigned long long* unit_counter = nullptr;  // [0] two-ended tile counter of the persistent kernel, [1] its watchdog flag
   Camera* cam = nullptr;                    // camera block of the render in flight (read with scalar loads)
-  unsigned long long* ray_total = nullptr;  // rays traced (stats)
+  unsigned long long* ray_total = nullptr;  // 4 words: [0] rays traced, [1] NaN radiance channels, [2] clamped ones (stats)
 };
 
 struct rt_ctx {
@@ -1091,6 +1114,9 @@ struct rt_ctx {
   int fused_kr_sync = 8;  // regeneration threshold of the bounce-synchronous schedule (small scenes)
   int global_prims = 1;  // scene upload: keep huge spheres out of the tree and test them first (Scene::n_global)
   int fused_feedback = 1;
+  hipStream_t fb_stream = nullptr;  // stream of the frame that recorded d_tile_class (feedback is only ordered through it)
+  uint32_t last_global_types[4] = {0, 0, 0, 0};  // global primitives of the last instrumented render's scene, by type
+  int dbg_watchdog_polls = 0;       // diagnostic: polls before a wave with nothing to do gives up (0 = 2^24)
   unsigned char* d_tile_class = nullptr;
   uint32_t* d_tile_order = nullptr;
   size_t tile_cap = 0;
@@ -1107,7 +1133,29 @@ struct rt_ctx {
   bool timing_pending = false;
   rt_stats stats{};
   int n_cu = 256;
+  // Device staging of the entry points that take HOST pointers (rt_render: the frame; rt_resolve: sums, f64 and u8
+  // outputs; rt_intersect: rays and hits): grow-only, kept until rt_shutdown, so that a caller that renders pass after
+  // pass (Camera::render_progressive) does not pay a hipMalloc + hipFree pair per call.
+  void* stage[3] = {nullptr, nullptr, nullptr};
+  size_t stage_cap[3] = {0, 0, 0};
 };
+
+static int ensure_stage(rt_ctx* ctx, int slot, size_t bytes) {
+  if (ctx->stage_cap[slot] >= bytes) return RT_OK;
+  if (ctx->stage[slot]) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)rti::dev_free(ctx->stage[slot]);
+    ctx->stage[slot] = nullptr;
+    ctx->stage_cap[slot] = 0;
+  }
+  hipError_t e = rti::dev_malloc(&ctx->stage[slot], bytes);
+  if (e != hipSuccess) {
+    ctx->err = std::string("device staging buffer: ") + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP;
+  }
+  ctx->stage_cap[slot] = bytes;
+  return RT_OK;
+}
 
 static std::string g_init_err;
 
@@ -1190,15 +1238,15 @@ int rt_init(int device_id, rt_ctx** out) {
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
   ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-  if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipEventCreate(&ctx->ev_a)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipEventCreate(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&ctx->own.ray_total, sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->own.unit_counter, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->own.cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(ctx->own.ray_total, 0, sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = rti::stream_create(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = rti::event_create(&ctx->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = rti::event_create(&ctx->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = rti::event_create(&ctx->ev_a)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = rti::event_create(&ctx->ev_b)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = rti::dev_malloc(&ctx->own.ray_total, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->own.unit_counter, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->own.cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(ctx->own.ray_total, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   ctx->last_ray_total = ctx->own.ray_total;
   {
     // rt_render_device_noalloc: this device's copy of the file-scope array `scratch`.  The array's name is only a
@@ -1212,13 +1260,13 @@ int rt_init(int device_id, rt_ctx** out) {
     ctx->fixed.unit_counter = reinterpret_cast<unsigned long long*>(ctl + 768);
   }
   // the partner workgroups' stream and fork / join events (launch_partner): created here so that no render call has to
-  if ((e = hipStreamCreateWithFlags(&ctx->partner_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-  if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_bins, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_timeline, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::stream_create(&ctx->partner_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  if ((e = rti::event_create(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = rti::event_create(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = rti::dev_malloc(&ctx->d_trav, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->d_bins, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->d_dbg, 16 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->d_timeline, 16 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->d_dbg, 0, 16 * sizeof(float))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMemset(ctx->d_trav, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   // noise jump table: entry [byte position i][value v] = short_jump(state with only that byte set)
@@ -1231,7 +1279,7 @@ int rt_init(int device_id, rt_ctx** out) {
       uint32_t* t = &tab[(size_t)(i * 256 + v) * 4];
       t[0] = (uint32_t)s[0]; t[1] = (uint32_t)(s[0] >> 32); t[2] = (uint32_t)s[1]; t[3] = (uint32_t)(s[1] >> 32);
     }
-  if ((e = hipMalloc(&ctx->d_noise_table, tab.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->d_noise_table, tab.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemcpy(ctx->d_noise_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
     return bail("hipMemcpy", e);
   *out = ctx;
@@ -1239,7 +1287,7 @@ int rt_init(int device_id, rt_ctx** out) {
 }
 
 static void free_work(rt_ctx* ctx) {
-  if (ctx->wb.slab) (void)hipFree(ctx->wb.slab);
+  if (ctx->wb.slab) (void)rti::dev_free(ctx->wb.slab);
   ctx->wb = WorkBuffers();
 }
 
@@ -1248,25 +1296,27 @@ int rt_shutdown(rt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_work(ctx);
-  if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-  if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
-  if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-  if (ctx->own.ray_total) (void)hipFree(ctx->own.ray_total);
-  if (ctx->own.unit_counter) (void)hipFree(ctx->own.unit_counter);
-  if (ctx->own.cam) (void)hipFree(ctx->own.cam);
-  if (ctx->d_trav) (void)hipFree(ctx->d_trav);
-  if (ctx->d_bins) (void)hipFree(ctx->d_bins);
-  if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
-  if (ctx->d_timeline) (void)hipFree(ctx->d_timeline);
-  if (ctx->d_noise_table) (void)hipFree(ctx->d_noise_table);
-  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-  if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
-  if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->partner_stream) (void)hipStreamDestroy(ctx->partner_stream);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->d_counts) (void)rti::dev_free(ctx->d_counts);
+  if (ctx->d_tile_class) (void)rti::dev_free(ctx->d_tile_class);
+  if (ctx->d_tile_order) (void)rti::dev_free(ctx->d_tile_order);
+  if (ctx->own.ray_total) (void)rti::dev_free(ctx->own.ray_total);
+  if (ctx->own.unit_counter) (void)rti::dev_free(ctx->own.unit_counter);
+  if (ctx->own.cam) (void)rti::dev_free(ctx->own.cam);
+  if (ctx->d_trav) (void)rti::dev_free(ctx->d_trav);
+  if (ctx->d_bins) (void)rti::dev_free(ctx->d_bins);
+  if (ctx->d_dbg) (void)rti::dev_free(ctx->d_dbg);
+  if (ctx->d_timeline) (void)rti::dev_free(ctx->d_timeline);
+  if (ctx->d_noise_table) (void)rti::dev_free(ctx->d_noise_table);
+  for (int i = 0; i < 3; i++)
+    if (ctx->stage[i]) (void)rti::dev_free(ctx->stage[i]);
+  if (ctx->ev_start) (void)rti::event_destroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)rti::event_destroy(ctx->ev_stop);
+  if (ctx->ev_a) (void)rti::event_destroy(ctx->ev_a);
+  if (ctx->ev_b) (void)rti::event_destroy(ctx->ev_b);
+  if (ctx->ev_fork) (void)rti::event_destroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)rti::event_destroy(ctx->ev_join);
+  if (ctx->partner_stream) (void)rti::stream_destroy(ctx->partner_stream);
+  if (ctx->stream) (void)rti::stream_destroy(ctx->stream);
   delete ctx;
   return RT_OK;
 }
@@ -1307,6 +1357,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_slots = (int)value;
   } else if (k == "dbg_main_cap") {
     ctx->dbg_main_cap = (int)std::max<int64_t>(0, std::min<int64_t>(value, 65536));
+  } else if (k == "dbg_watchdog_polls") {
+    if (value < 0 || value > (1 << 24)) return fail(ctx, RT_E_INVALID_ARG, "dbg_watchdog_polls must be in 0..2^24");
+    ctx->dbg_watchdog_polls = (int)value;
   } else if (k == "fused_kr_sync") {
     if (value < 1 || value > 64) return fail(ctx, RT_E_INVALID_ARG, "fused_kr_sync must be in 1..64");
     ctx->fused_kr_sync = (int)value;
@@ -1374,15 +1427,15 @@ static int validate_texture_graph(rt_ctx* ctx, const rt_scene_desc* d) {
 int rt_scene_free(rt_ctx* ctx, rt_scene* s) {
   if (!s) return RT_OK;
   if (ctx) (void)hipSetDevice(ctx->device);
-  if (s->d_nodes) (void)hipFree(s->d_nodes);
-  if (s->d_nodes4) (void)hipFree(s->d_nodes4);
-  if (s->d_nodes4h) (void)hipFree(s->d_nodes4h);
-  if (s->d_global) (void)hipFree(s->d_global);
-  if (s->d_prims) (void)hipFree(s->d_prims);
-  if (s->d_mats) (void)hipFree(s->d_mats);
-  if (s->d_texs) (void)hipFree(s->d_texs);
-  if (s->d_texels) (void)hipFree(s->d_texels);
-  if (s->d_spheres) (void)hipFree(s->d_spheres);
+  if (s->d_nodes) (void)rti::dev_free(s->d_nodes);
+  if (s->d_nodes4) (void)rti::dev_free(s->d_nodes4);
+  if (s->d_nodes4h) (void)rti::dev_free(s->d_nodes4h);
+  if (s->d_global) (void)rti::dev_free(s->d_global);
+  if (s->d_prims) (void)rti::dev_free(s->d_prims);
+  if (s->d_mats) (void)rti::dev_free(s->d_mats);
+  if (s->d_texs) (void)rti::dev_free(s->d_texs);
+  if (s->d_texels) (void)rti::dev_free(s->d_texels);
+  if (s->d_spheres) (void)rti::dev_free(s->d_spheres);
   delete s;
   return RT_OK;
 }
@@ -1529,8 +1582,9 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     fix(bvh.root);
   }
   sc->view.n_global = n_global;
+  for (int g = 0; g < n_global; g++) sc->global_types[std::min<uint32_t>(d->prims[globals[g]].type, 3u)]++;
   sc->view.tree_empty = tiny ? 1 : 0;
-  HIP_TRY(ctx, hipMalloc(&sc->d_global, RT_MAX_GLOBAL * sizeof(int32_t)));
+  HIP_TRY(ctx, rti::dev_malloc(&sc->d_global, RT_MAX_GLOBAL * sizeof(int32_t)));
   HIP_TRY(ctx, hipMemcpy(sc->d_global, globals, RT_MAX_GLOBAL * sizeof(int32_t), hipMemcpyHostToDevice));
   sc->view.global_list = sc->d_global;
   sc->bvh_depth = bvh.depth;
@@ -1602,7 +1656,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   }
   static_assert(sizeof(rtb::FlatNode) == sizeof(BvhNode), "node layout mismatch");
   size_t n_nodes = std::max<size_t>(bvh.nodes.size(), 1);
-  HIP_TRY(ctx, hipMalloc(&sc->d_nodes, n_nodes * sizeof(BvhNode)));
+  HIP_TRY(ctx, rti::dev_malloc(&sc->d_nodes, n_nodes * sizeof(BvhNode)));
   if (!bvh.nodes.empty())
     HIP_TRY(ctx, hipMemcpy(sc->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
   {
@@ -1632,22 +1686,22 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
           }
           hn[i].child[k] = wide.nodes[i].child[k];
         }
-      HIP_TRY(ctx, hipMalloc(&sc->d_nodes4h, hn.size() * sizeof(HalfNode)));
+      HIP_TRY(ctx, rti::dev_malloc(&sc->d_nodes4h, hn.size() * sizeof(HalfNode)));
       HIP_TRY(ctx, hipMemcpy(sc->d_nodes4h, hn.data(), hn.size() * sizeof(HalfNode), hipMemcpyHostToDevice));
       sc->view.nodes4h = sc->d_nodes4h;
     }
-    HIP_TRY(ctx, hipMalloc(&sc->d_nodes4, std::max<size_t>(wide.nodes.size(), 1) * sizeof(rtb::WideNode)));
+    HIP_TRY(ctx, rti::dev_malloc(&sc->d_nodes4, std::max<size_t>(wide.nodes.size(), 1) * sizeof(rtb::WideNode)));
     if (!wide.nodes.empty())
       HIP_TRY(ctx, hipMemcpy(sc->d_nodes4, wide.nodes.data(), wide.nodes.size() * sizeof(rtb::WideNode), hipMemcpyHostToDevice));
   }
-  HIP_TRY(ctx, hipMalloc(&sc->d_prims, prims.size() * sizeof(Prim)));
+  HIP_TRY(ctx, rti::dev_malloc(&sc->d_prims, prims.size() * sizeof(Prim)));
   HIP_TRY(ctx, hipMemcpy(sc->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMalloc(&sc->d_mats, mats.size() * sizeof(Material)));
+  HIP_TRY(ctx, rti::dev_malloc(&sc->d_mats, mats.size() * sizeof(Material)));
   HIP_TRY(ctx, hipMemcpy(sc->d_mats, mats.data(), mats.size() * sizeof(Material), hipMemcpyHostToDevice));
-  HIP_TRY(ctx, hipMalloc(&sc->d_texs, texs.size() * sizeof(Texture)));
+  HIP_TRY(ctx, rti::dev_malloc(&sc->d_texs, texs.size() * sizeof(Texture)));
   HIP_TRY(ctx, hipMemcpy(sc->d_texs, texs.data(), texs.size() * sizeof(Texture), hipMemcpyHostToDevice));
   if (d->n_texel_bytes) {
-    HIP_TRY(ctx, hipMalloc(&sc->d_texels, (d->n_texel_bytes + 3) & ~3ull));
+    HIP_TRY(ctx, rti::dev_malloc(&sc->d_texels, (d->n_texel_bytes + 3) & ~3ull));
     HIP_TRY(ctx, hipMemcpy(sc->d_texels, d->texels, d->n_texel_bytes, hipMemcpyHostToDevice));
   }
   if (sc->spheres_only) {
@@ -1660,7 +1714,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       r.type = prims[i].type;
       r.mat = prims[i].mat;
     }
-    HIP_TRY(ctx, hipMalloc(&sc->d_spheres, recs.size() * sizeof(SphereRec)));
+    HIP_TRY(ctx, rti::dev_malloc(&sc->d_spheres, recs.size() * sizeof(SphereRec)));
     HIP_TRY(ctx, hipMemcpy(sc->d_spheres, recs.data(), recs.size() * sizeof(SphereRec), hipMemcpyHostToDevice));
   }
   sc->view.spheres = sc->d_spheres;
@@ -1749,21 +1803,18 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
   if (!scene || (n && (!rays || !out_hits))) return fail(ctx, RT_E_INVALID_ARG, "rt_intersect: NULL argument");
   if (n == 0) return RT_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const uint64_t CH = 1u << 22;
+  const uint64_t CH = 1u << 20;  // rays per staged chunk (the staging buffers are kept: 56 + 88 B per ray)
   if ((ctx->probe_tree == 1 || ctx->probe_tree == 2) && scene->wide_stack + 2 > RT_STACK_DEPTH)
     return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: the four-wide tree of this scene needs a deeper stack than the probe has");
   if ((ctx->probe_tree == 2 || ctx->probe_tree == 4) && !scene->half_ok)
     return fail(ctx, RT_E_UNSUPPORTED, "rt_intersect: scene coordinates exceed the binary16 range");
   uint64_t chunk = n < CH ? n : CH;
-  rt_ray* d_rays = nullptr;
-  rt_hit* d_hits = nullptr;
-  HIP_TRY(ctx, hipMalloc(&d_rays, chunk * sizeof(rt_ray)));
-  hipError_t e = hipMalloc(&d_hits, chunk * sizeof(rt_hit));
-  if (e != hipSuccess) {
-    (void)hipFree(d_rays);
-    return fail(ctx, RT_E_OOM, "rt_intersect: hipMalloc failed");
-  }
-  int rc = RT_OK;
+  int rc = ensure_stage(ctx, 1, chunk * sizeof(rt_ray));
+  if (rc == RT_OK) rc = ensure_stage(ctx, 2, chunk * sizeof(rt_hit));
+  if (rc != RT_OK) return rc;
+  rt_ray* d_rays = static_cast<rt_ray*>(ctx->stage[1]);
+  rt_hit* d_hits = static_cast<rt_hit*>(ctx->stage[2]);
+  hipError_t e = hipSuccess;
   for (uint64_t off = 0; off < n && rc == RT_OK; off += chunk) {
     uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n - off);
     uint32_t blocks = std::min<uint32_t>((m + RT_BLOCK - 1) / RT_BLOCK, (uint32_t)ctx->n_cu * 8);
@@ -1781,8 +1832,6 @@ int rt_intersect(rt_ctx* ctx, const rt_scene* scene, const rt_ray* rays, uint64_
     if ((e = hipMemcpyAsync(out_hits + off, d_hits, (size_t)m * sizeof(rt_hit), hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { rc = RT_E_HIP; break; }
   }
-  (void)hipFree(d_rays);
-  (void)hipFree(d_hits);
   if (rc != RT_OK && e != hipSuccess) ctx->err = std::string("rt_intersect: ") + hipGetErrorString(e);
   return rc;
 }
@@ -1796,7 +1845,7 @@ static int ensure_work(rt_ctx* ctx, size_t cap, uint32_t depth) {
     const size_t capa = (cap + 63) & ~(size_t)63;
     const size_t per_q = capa * (7 * 8 + 3 * 4 + 3 * 4);
     const size_t total = 2 * per_q + capa * (4 + 8) + capa * 12 + capa * 4;
-    HIP_TRY(ctx, hipMalloc(&ctx->wb.slab, total));
+    HIP_TRY(ctx, rti::dev_malloc(&ctx->wb.slab, total));
     char* p = (char*)ctx->wb.slab;
     auto take = [&](size_t bytes) { char* r = p; p += bytes; return r; };
     ctx->wb.hits.t = (double*)take(capa * 8);
@@ -1819,10 +1868,10 @@ static int ensure_work(rt_ctx* ctx, size_t cap, uint32_t depth) {
   }
   if (ctx->counts_cap < (size_t)depth + 2) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_counts) (void)rti::dev_free(ctx->d_counts);
     ctx->d_counts = nullptr;
     ctx->counts_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_counts, ((size_t)depth + 2) * 4));
+    HIP_TRY(ctx, rti::dev_malloc(&ctx->d_counts, ((size_t)depth + 2) * 4));
     ctx->counts_cap = (size_t)depth + 2;
   }
   return RT_OK;
@@ -2057,6 +2106,15 @@ static int launch_variant(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, 
   return launch_fused<F, KIND, BLOCK, StackT, false, false>(ctx, scene, dc, fp, smem, st);
 }
 
+// ... or the instrumented build of the same instance (option fused_stats: bench.py's own-tree operation counts)
+template <uint32_t F, int KIND, int BLOCK, class StackT>
+static int launch_variant_or_stats(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp, size_t smem,
+                                   hipStream_t st) {
+  if (!ctx->fused_stats) return launch_variant<F, KIND, BLOCK, StackT>(ctx, scene, dc, fp, smem, st);
+  if (use_resume(ctx, scene)) return launch_fused<F, KIND, BLOCK, StackT, true, true>(ctx, scene, dc, fp, smem, st);
+  return launch_fused<F, KIND, BLOCK, StackT, true, false>(ctx, scene, dc, fp, smem, st);
+}
+
 static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, const Camera& dc, uint64_t seed,
                         uint32_t sample_begin, uint32_t sample_stride, uint32_t K, float* d_out_sum, hipStream_t st) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->fs->unit_counter, 0, 2 * sizeof(unsigned long long), st));  // [0] tile counter, [1] watchdog flag
@@ -2066,6 +2124,14 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   memset(&fp, 0, sizeof(fp));
   fp.K = K; fp.s_begin = sample_begin; fp.s_stride = sample_stride;
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
+  fp.poll_limit = ctx->dbg_watchdog_polls > 0 ? (uint32_t)ctx->dbg_watchdog_polls : (1u << 24);
+  {
+    int lg = 0;  // ceil(log2 K)
+    while ((1ull << lg) < (unsigned long long)K) lg++;
+    const int bits = std::min(40, 43 - lg);  // K * 2^20 * 2^bits <= 2^63
+    fp.fix_scale = std::ldexp(1.0f, bits);
+    fp.fix_inv = std::ldexp(1.0, -bits);
+  }
   const uint32_t sdepth = (uint32_t)std::max(1, scene->bvh_depth + 1);
   fp.stack_depth = sdepth;
   fp.kb = (uint32_t)ctx->fused_kb; fp.kn = (uint32_t)ctx->fused_kn; fp.kr = use_resume(ctx, scene) ? (uint32_t)ctx->fused_kr : (uint32_t)ctx->fused_kr_sync;
@@ -2144,11 +2210,11 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   if (ctx->fused_feedback && in_lds && ctx->fs == &ctx->own) {
     if (fp.n_tiles > ctx->tile_cap) {
       HIP_TRY(ctx, hipStreamSynchronize(st));
-      if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
-      if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+      if (ctx->d_tile_class) (void)rti::dev_free(ctx->d_tile_class);
+      if (ctx->d_tile_order) (void)rti::dev_free(ctx->d_tile_order);
       ctx->d_tile_class = nullptr; ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->fb_valid = false;
-      HIP_TRY(ctx, hipMalloc(&ctx->d_tile_class, fp.n_tiles));
-      HIP_TRY(ctx, hipMalloc(&ctx->d_tile_order, (size_t)fp.n_tiles * sizeof(uint32_t)));
+      HIP_TRY(ctx, rti::dev_malloc(&ctx->d_tile_class, fp.n_tiles));
+      HIP_TRY(ctx, rti::dev_malloc(&ctx->d_tile_order, (size_t)fp.n_tiles * sizeof(uint32_t)));
       ctx->tile_cap = fp.n_tiles;
     }
     uint64_t key = 0xCBF29CE484222325ull;
@@ -2160,6 +2226,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     mix(cam, sizeof(*cam));
     mix(&fp.n_tiles, sizeof(fp.n_tiles));
     mix(fp.lvl_begin, sizeof(fp.lvl_begin)); mix(fp.lvl_y0, sizeof(fp.lvl_y0)); mix(fp.lvl_shift, sizeof(fp.lvl_shift));
+    // The classes are written by the previous frame's kernels and read twice by k_order_tiles: that is ordered only
+    // through the stream, so a frame issued on another stream than its predecessor starts from image order.
+    if (ctx->fb_stream != st) ctx->fb_valid = false;
+    ctx->fb_stream = st;
     if (ctx->fb_valid && key == ctx->fb_key) {
       hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, st, ctx->d_tile_class, ctx->d_tile_order, fp.n_tiles);
       fp.order = ctx->d_tile_order;
@@ -2182,7 +2252,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   if (ctx->fused_stats) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0xFF, sizeof(unsigned long long), st));     // [0]: minimum
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline + 1, 0, 7 * sizeof(unsigned long long), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline + 1, 0, 15 * sizeof(unsigned long long), st));
+    for (int k = 0; k < 4; k++) ctx->last_global_types[k] = scene->global_types[k];
     fp.timeline = ctx->d_timeline;
   }
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
@@ -2190,8 +2261,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
       if (use_resume(ctx, scene)) rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true, true>(ctx, scene, dc, fp, lds_1024, st);
       else rc = launch_fused<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, true, false>(ctx, scene, dc, fp, lds_1024, st);
     } else if (lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
-    else if (tex_only == RT_F_TEX_IMAGE) rc = launch_variant<RT_F_TEX_IMAGE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
-    else if (!(tex_only & RT_F_TEX_IMAGE)) rc = launch_variant<RT_F_TEX_CHECKER | RT_F_TEX_NOISE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else if (tex_only == RT_F_TEX_IMAGE) rc = launch_variant_or_stats<RT_F_TEX_IMAGE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
+    else if (!(tex_only & RT_F_TEX_IMAGE)) rc = launch_variant_or_stats<RT_F_TEX_CHECKER | RT_F_TEX_NOISE, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
     else rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_LDS, 1024, int16_t>(ctx, scene, dc, fp, lds_1024, st);
   } else if (!scene->spheres_only && ctx->fused_lds && small_ids && lds_generic_1024 <= 160 * 1024) {
     if (tex_only == 0 && ctx->fused_stats) {  // instrumented build of the Cornell instance (both schedules)
@@ -2275,7 +2346,7 @@ static int render_device_impl(rt_ctx* ctx, const rt_scene* scene, const rt_camer
   ctx->stats = rt_stats();
   ctx->ms_bin = 0.f;
   HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->ray_total, 0, sizeof(unsigned long long), st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->ray_total, 0, 4 * sizeof(unsigned long long), st));
   ctx->last_ray_total = ctx->fs->ray_total;
   ctx->last_watchdog = nullptr;
   if (K > 0 && cam->max_depth > 0) {
@@ -2300,8 +2371,10 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
   return render_device_impl(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out_sum, hip_stream, false);
 }
 
-// Same render with every scratch buffer (frame accumulators, unit counter, camera block, ray counter) in the
-// file-scope device array `scratch`: no hipMalloc / hipFree / stream or event creation on this path.
+// Same render with every scratch buffer (the camera block of the frame in flight, the two-ended tile counter, the
+// watchdog flag, the ray / anomaly counters: 1 KiB of control words) in the file-scope device array `scratch`: no
+// hipMalloc / hipFree / stream or event creation on this path (rt_stats.lib_alloc_calls does not move across it).
+// RT_NOALLOC_MAX_PIXELS is a stated limit kept for interface stability; no buffer imposes it.
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
                              uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
   return render_device_impl(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out_sum, hip_stream, true);
@@ -2314,17 +2387,28 @@ int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t
   if (cam->width == 0 || cam->height == 0) return fail(ctx, RT_E_INVALID_ARG, "camera: zero image size");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)cam->width * cam->height * 3 * sizeof(float);
-  float* d_out = nullptr;
-  HIP_TRY(ctx, hipMalloc(&d_out, bytes));
-  int rc = rt_render_device(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out, nullptr);
+  int rc = ensure_stage(ctx, 0, bytes);
+  if (rc != RT_OK) return rc;
+  float* d_out = static_cast<float*>(ctx->stage[0]);
+  rc = rt_render_device(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out, nullptr);
   if (rc == RT_OK) {
     hipError_t e = hipMemcpyAsync(out_sum, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(ctx, RT_E_HIP, std::string("rt_render: ") + hipGetErrorString(e));
+    else rc = rt_internal_frame_status(ctx);  // a frame cut short by the scheduler's watchdog is an error, not a frame
   }
-  (void)hipFree(d_out);
   return rc;
 }
+
+}  // extern "C"
+int rt_internal_frame_status(rt_ctx* ctx) {
+  if (!ctx->last_watchdog) return RT_OK;  // wavefront mode, or nothing rendered
+  uint32_t flag = 0;
+  HIP_TRY(ctx, hipMemcpy(&flag, ctx->last_watchdog, sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag) return fail(ctx, RT_E_INTERNAL, "fused kernel: a wave found no work for seconds and gave up (scheduler watchdog); the frame is incomplete");
+  return RT_OK;
+}
+extern "C" {
 
 int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
   if (!ctx || !out) return RT_E_INVALID_ARG;
@@ -2334,10 +2418,20 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     float ms = 0;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->stats.ms_total = ms;
-    unsigned long long rays = 0;
-    HIP_TRY(ctx, hipMemcpy(&rays, ctx->last_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
-    ctx->stats.rays = rays;
+    unsigned long long rays[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpy(rays, ctx->last_ray_total, sizeof(rays), hipMemcpyDeviceToHost));
+    ctx->stats.rays = rays[0];
+    ctx->stats.samples_nan = rays[1];
+    ctx->stats.samples_clamped = rays[2];
     HIP_TRY(ctx, hipMemcpy(ctx->stats.dbg, ctx->d_dbg, 16 * sizeof(float), hipMemcpyDeviceToHost));
+    if (ctx->fused_stats) {  // exact counters of the instrumented build (rt_stats.dbg_counts)
+      unsigned long long tl[16];
+      HIP_TRY(ctx, hipMemcpy(tl, ctx->d_timeline, sizeof(tl), hipMemcpyDeviceToHost));
+      ctx->stats.dbg_counts[0] = tl[7];
+      // leaf tests by type + the global primitives every ray tests before it enters the tree
+      for (int k = 0; k < 4; k++) ctx->stats.dbg_counts[1 + k] = tl[8 + k] + (uint64_t)ctx->last_global_types[k] * rays[0];
+      for (int k = 0; k < 3; k++) ctx->stats.dbg_counts[5 + k] = tl[4 + k];
+    }
     if (ctx->fused_stats && getenv("RT_VERBOSE")) {
       unsigned long long tl[8];
       HIP_TRY(ctx, hipMemcpy(tl, ctx->d_timeline, sizeof(tl), hipMemcpyDeviceToHost));
@@ -2357,9 +2451,8 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
         ctx->stats.dbg[14] = (float)taken[0];
         ctx->stats.dbg[15] = (float)taken[1];
       }
-      uint32_t flag = 0;
-      HIP_TRY(ctx, hipMemcpy(&flag, ctx->last_watchdog, sizeof(flag), hipMemcpyDeviceToHost));
-      if (flag) return fail(ctx, RT_E_INTERNAL, "fused kernel: a wave found no work for seconds and gave up (scheduler watchdog); the frame is incomplete");
+      const int frc = rt_internal_frame_status(ctx);
+      if (frc != RT_OK) return frc;
     }
     unsigned long long trav[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpy(trav, ctx->d_trav, sizeof(trav), hipMemcpyDeviceToHost));
@@ -2369,6 +2462,7 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
     ctx->timing_pending = false;
   }
   *out = ctx->stats;
+  out->lib_alloc_calls = rti::g_alloc_calls.load();
   return RT_OK;
 }
 
@@ -2395,23 +2489,20 @@ int rt_resolve(rt_ctx* ctx, const float* sum, uint32_t width, uint32_t height, u
   if (!sum || width == 0 || height == 0) return fail(ctx, RT_E_INVALID_ARG, "rt_resolve: bad argument");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t n = (size_t)width * height * 3;
-  float* d_sum = nullptr;
-  double* d_rgb = nullptr;
-  uint8_t* d_u8 = nullptr;
-  int rc = RT_OK;
-  hipError_t e = hipMalloc(&d_sum, n * 4);
-  if (e == hipSuccess && out_rgb) e = hipMalloc(&d_rgb, n * 8);
-  if (e == hipSuccess && out_rgb8) e = hipMalloc(&d_u8, n);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_sum, sum, n * 4, hipMemcpyHostToDevice, ctx->stream);
+  int rc = ensure_stage(ctx, 0, n * 4);
+  if (rc == RT_OK && out_rgb) rc = ensure_stage(ctx, 1, n * 8);
+  if (rc == RT_OK && out_rgb8) rc = ensure_stage(ctx, 2, n);
+  if (rc != RT_OK) return rc;
+  float* d_sum = static_cast<float*>(ctx->stage[0]);
+  double* d_rgb = out_rgb ? static_cast<double*>(ctx->stage[1]) : nullptr;
+  uint8_t* d_u8 = out_rgb8 ? static_cast<uint8_t*>(ctx->stage[2]) : nullptr;
+  hipError_t e = hipMemcpyAsync(d_sum, sum, n * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     rc = rt_resolve_device(ctx, d_sum, width, height, spp, gamma, d_rgb, d_u8, nullptr);
     if (rc == RT_OK && out_rgb) e = hipMemcpyAsync(out_rgb, d_rgb, n * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (rc == RT_OK && e == hipSuccess && out_rgb8) e = hipMemcpyAsync(out_rgb8, d_u8, n, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   }
-  if (d_sum) (void)hipFree(d_sum);
-  if (d_rgb) (void)hipFree(d_rgb);
-  if (d_u8) (void)hipFree(d_u8);
   if (rc == RT_OK && e != hipSuccess) rc = fail(ctx, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, std::string("rt_resolve: ") + hipGetErrorString(e));
   return rc;
 }

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/rt_abi.h"
+#include "rt_internal.h"
 
 #define RT_MULTI_MAX_DEVICES 16
 
@@ -111,9 +112,9 @@ static void run_job(rt_multi* m, Worker& w, int index) {
   const Job& j = m->job_table[index];
   const size_t n_val = (size_t)j.cam->width * j.cam->height * 3;
   if (w.part_cap < n_val) {
-    if (w.d_part) (void)hipFree(w.d_part);
+    if (w.d_part) (void)rti::dev_free(w.d_part);
     w.d_part = nullptr; w.part_cap = 0;
-    if (hipMalloc(&w.d_part, n_val * sizeof(float)) != hipSuccess) { w.rc = RT_E_OOM; w.err = "hipMalloc of the partial frame failed"; return; }
+    if (rti::dev_malloc(&w.d_part, n_val * sizeof(float)) != hipSuccess) { w.rc = RT_E_OOM; w.err = "hipMalloc of the partial frame failed"; return; }
     w.part_cap = n_val;
   }
   w.rc = rt_render_device(w.ctx, w.scene, j.cam, j.seed, j.begin, j.end, j.stride, w.d_part, w.stream);
@@ -175,16 +176,16 @@ int rt_multi_shutdown(rt_multi* m) {
     (void)hipSetDevice(w.device);
     if (w.stream) (void)hipStreamSynchronize(w.stream);
     if (w.scene) rt_scene_free(w.ctx, w.scene);
-    if (w.d_part) (void)hipFree(w.d_part);
-    if (w.done) (void)hipEventDestroy(w.done);
-    if (w.stream) (void)hipStreamDestroy(w.stream);
+    if (w.d_part) (void)rti::dev_free(w.d_part);
+    if (w.done) (void)rti::event_destroy(w.done);
+    if (w.stream) (void)rti::stream_destroy(w.stream);
     if (w.ctx) rt_shutdown(w.ctx);
   }
   if (!m->w.empty() && m->w[0].ctx) (void)hipSetDevice(m->w[0].device);
-  if (m->d_total) (void)hipFree(m->d_total);
-  if (m->ev_t0) (void)hipEventDestroy(m->ev_t0);
-  if (m->ev_t1) (void)hipEventDestroy(m->ev_t1);
-  if (m->ev_t2) (void)hipEventDestroy(m->ev_t2);
+  if (m->d_total) (void)rti::dev_free(m->d_total);
+  if (m->ev_t0) (void)rti::event_destroy(m->ev_t0);
+  if (m->ev_t1) (void)rti::event_destroy(m->ev_t1);
+  if (m->ev_t2) (void)rti::event_destroy(m->ev_t2);
   delete m;
   return RT_OK;
 }
@@ -213,8 +214,8 @@ int rt_multi_init(const int* device_ids, int n_devices, rt_multi** out) {
     int rc = rt_init(w.device, &w.ctx);
     if (rc != RT_OK) return bail(rc, std::string("rt_multi_init: ") + rt_last_error(nullptr));
     hipError_t e = hipSetDevice(w.device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+    if (e == hipSuccess) e = rti::stream_create(&w.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = rti::event_create(&w.done, hipEventDisableTiming);
     if (e != hipSuccess) return bail(RT_E_HIP, std::string("rt_multi_init: ") + hipGetErrorString(e));
   }
   // the root (first device) reads the other devices' partial frames in place: peer access root -> peer
@@ -232,9 +233,9 @@ int rt_multi_init(const int* device_ids, int n_devices, rt_multi** out) {
     if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
     if (e != hipSuccess) return bail(RT_E_HIP, std::string("rt_multi_init: hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
   }
-  e = hipEventCreate(&m->ev_t0);
-  if (e == hipSuccess) e = hipEventCreate(&m->ev_t1);
-  if (e == hipSuccess) e = hipEventCreate(&m->ev_t2);
+  e = rti::event_create(&m->ev_t0);
+  if (e == hipSuccess) e = rti::event_create(&m->ev_t1);
+  if (e == hipSuccess) e = rti::event_create(&m->ev_t2);
   if (e != hipSuccess) return bail(RT_E_HIP, std::string("rt_multi_init: ") + hipGetErrorString(e));
   try {
     for (int i = 0; i < n_devices; i++) m->w[(size_t)i].thread = std::thread(worker_main, m, i);
@@ -280,9 +281,9 @@ static int render_sum(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t
   hipError_t e = hipSetDevice(root.device);
   if (e == hipSuccess && m->total_cap < n_val) {
     (void)hipStreamSynchronize(root.stream);
-    if (m->d_total) (void)hipFree(m->d_total);
+    if (m->d_total) (void)rti::dev_free(m->d_total);
     m->d_total = nullptr; m->total_cap = 0;
-    e = hipMalloc(&m->d_total, n_val * sizeof(float));
+    e = rti::dev_malloc(&m->d_total, n_val * sizeof(float));
     if (e == hipSuccess) m->total_cap = n_val;
   }
   if (e != hipSuccess) return mfail(m, e == hipErrorOutOfMemory ? RT_E_OOM : RT_E_HIP, std::string("rt_multi_render: ") + hipGetErrorString(e));
@@ -319,6 +320,18 @@ static int render_sum(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t
   return RT_OK;
 }
 
+// after the root stream has been synchronised (it waited for every device's render): a frame that a scheduler watchdog
+// cut short on any device is an error of the whole call
+static int frames_complete(rt_multi* m) {
+  for (Worker& w : m->w) {
+    (void)hipSetDevice(w.device);
+    const int rc = rt_internal_frame_status(w.ctx);
+    if (rc != RT_OK) return mfail(m, rc, "device " + std::to_string(w.device) + ": " + rt_last_error(w.ctx));
+  }
+  (void)hipSetDevice(m->w[0].device);
+  return RT_OK;
+}
+
 int rt_multi_render(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t sample_begin, uint32_t sample_end,
                     uint32_t sample_stride, float* out_sum) {
   if (!m) return RT_E_INVALID_ARG;
@@ -332,7 +345,7 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t s
   if (e == hipSuccess) e = hipStreamSynchronize(root.stream);
   if (e != hipSuccess) return mfail(m, RT_E_HIP, std::string("rt_multi_render: ") + hipGetErrorString(e));
   m->stats_valid = true;
-  return RT_OK;
+  return frames_complete(m);
 }
 
 int rt_multi_render_device(rt_multi* m, const rt_camera* cam, uint64_t seed, uint32_t sample_begin, uint32_t sample_end,
@@ -348,7 +361,7 @@ int rt_multi_render_device(rt_multi* m, const rt_camera* cam, uint64_t seed, uin
   if (e == hipSuccess) e = hipStreamSynchronize(root.stream);
   if (e != hipSuccess) return mfail(m, RT_E_HIP, std::string("rt_multi_render_device: ") + hipGetErrorString(e));
   m->stats_valid = true;
-  return RT_OK;
+  return frames_complete(m);
 }
 
 int rt_multi_get_stats(rt_multi* m, rt_multi_stats* out) {
@@ -362,11 +375,11 @@ int rt_multi_get_stats(rt_multi* m, rt_multi_stats* out) {
     if (hipEventElapsedTime(&ms, m->ev_t1, m->ev_t2) == hipSuccess) m->stats.ms_copy = ms;
     for (size_t i = 0; i < m->w.size() && i < RT_MULTI_MAX_DEVICES; i++) {
       rt_stats s;
-      if (rt_get_stats(m->w[i].ctx, &s) == RT_OK) {
-        m->stats.ms_render[i] = s.ms_total;
-        m->stats.paths += s.paths;
-        m->stats.rays += s.rays;
-      }
+      const int rc = rt_get_stats(m->w[i].ctx, &s);
+      if (rc != RT_OK) return mfail(m, rc, "device " + std::to_string(m->w[i].device) + ": " + rt_last_error(m->w[i].ctx));
+      m->stats.ms_render[i] = s.ms_total;
+      m->stats.paths += s.paths;
+      m->stats.rays += s.rays;
     }
   }
   *out = m->stats;

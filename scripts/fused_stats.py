@@ -43,9 +43,9 @@ def run(stats, **opts):
         if d[12] > 0:  # cycle shares of the phases (s_memtime deltas, per wave)
             out["cycles"] = {n: round(d[8 + i] / d[12], 3) for i, n in enumerate(["node", "leaf", "shade", "regen"])}
             out["cycles"]["wait_for_work"] = round(d[14] / d[12], 3)
-            out["mean_exhaustion_age_over_max_lifetime"] = round(d[15] / 4096 / d[13], 3)
+            out["mean_exhaustion_age_over_max_lifetime"] = round(d[15] / int(next((a.split("=")[1] for a in sys.argv if a.startswith("--waves=")), 4096)) / d[13], 3)
             # mean wave lifetime over the longest one: what the frame's tail costs
-            n_waves = 4096
+            n_waves = int(next((a.split("=")[1] for a in sys.argv if a.startswith("--waves=")), 4096))  # workgroups x waves (C5: 256 x 12)
             out["mean_over_max_lifetime"] = round(d[12] / n_waves / d[13], 3)
     print(json.dumps(out), flush=True)
 
@@ -98,12 +98,9 @@ if "--half" in sys.argv:  # HBM-resident instances: binary16 planes + LDS cache 
 if "--partner" in sys.argv:  # LDS-resident spheres instance with / without its 256-thread partner workgroups
     for v in (1, 0, 1, 0, 1, 0):
         run(False, fused_partner=v)
-if "--tail" in sys.argv:  # the last `fused_tail` passes' worth of samples in units of `fused_tail_ku` sample indices
-    for t, k in ((0, 0), (4, 0), (4, 4), (2, 3), (6, 4), (4, 5), (4, 1), (0, 0), (4, 0)):
-        run(False, fused_tail=t, fused_tail_ku=k)
-if "--tail0" in sys.argv:
-    for t in (4, 0, 4, 0):
-        run(False, fused_tail=t)
+if "--tail" in sys.argv:  # heights (per mille of the frame's rows) of the 4x4 / 2x2 bands at the end of the tile list
+    for t4, t2 in ((50, 30), (0, 0), (50, 0), (100, 30), (25, 15), (50, 60), (50, 30), (0, 0)):
+        run(False, fused_tail4=t4, fused_tail2=t2)
 if "--ku5" in sys.argv:
     for ku in (0, 8, 4, 2, 0, 8, 4):
         run(False, fused_ku=ku)

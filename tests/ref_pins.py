@@ -5,7 +5,7 @@ Edge map: luminance of the gamma-corrected image, Gaussian sigma 1.5 px (the com
 not recorded), Sobel gradient, non-maximum suppression along the quantised gradient direction, threshold 0.04 / px.
 What survives are sphere silhouettes, checker transitions and coast lines: one-pixel-wide curves whose POSITION depends
 on the sphere centres and radii (scene.rs:114-143), the camera (builder.rs:74-135), the checker's inv_scale and
-parity (texture.rs:50-60) and the sphere uv mapping (hittable/sphere.rs:37-46), and not on spp or the RNG stream."""
+parity (texture.rs:50-60) and the sphere uv mapping (hittable/geometry.rs:30-34), and not on spp or the RNG stream."""
 import numpy as np
 from scipy import ndimage as ndi
 

@@ -79,3 +79,73 @@ def test_huge_sample_stride_selects_one_sample(ctx):
     for stride in (0xFFFFFFFF, 0x80000000, 13):  # K = ceil((16 - 3) / stride) = 1, computed in 64 bits
         assert np.array_equal(dev.render_sums(cam, seed=2, sample_begin=3, sample_end=16, sample_stride=stride), one)
     dev.close()
+
+
+def test_frame_cut_short_by_the_watchdog_is_an_error_not_a_frame(ctx):
+    """the scheduler's watchdog (a wave that finds nothing to do for ~2^24 polls gives up instead of hanging
+    the GPU) used to be visible in rt_get_stats only.  With the poll limit shrunk to one poll the flag is raised on any
+    frame whose waves ever wait for a tile to be opened: the blocking entry points must then return RT_E_INTERNAL, and
+    the asynchronous one must report it through rt_get_stats; the next frame with the normal limit is fine again."""
+    import torch
+    g = ra.Scene("book_cover", 320, 16 / 9, "uniform", 16, 50)
+    dev = ra.DeviceScene(ctx, C.byref(g.desc))
+    cam = g.camera_copy()
+    good = dev.render_sums(cam, seed=3)
+    ctx.set_option("dbg_watchdog_polls", 1)
+    try:
+        with pytest.raises(ra.RtError) as e:
+            dev.render_sums(cam, seed=3)
+        assert e.value.code == ra.RT_E_INTERNAL and "watchdog" in str(e.value)
+        d = torch.zeros((g.height, g.width, 3), dtype=torch.float32, device="cuda")
+        dev.render_device(cam, d.data_ptr(), seed=3)  # asynchronous: the call itself cannot know
+        ctx.synchronize()
+        with pytest.raises(ra.RtError) as e:
+            ctx.stats()
+        assert e.value.code == ra.RT_E_INTERNAL
+        m = ra.MultiContext([0, 0])
+        try:
+            m.set_option("dbg_watchdog_polls", 1)
+            m.upload(C.byref(g.desc))
+            with pytest.raises(ra.RtError) as e:
+                m.render_sums(cam, seed=3)
+            assert e.value.code == ra.RT_E_INTERNAL and "watchdog" in str(e.value)
+            with pytest.raises(ra.RtError):
+                m.stats()  # rt_multi_get_stats propagates the failing rt_get_stats
+        finally:
+            m.close()
+    finally:
+        ctx.set_option("dbg_watchdog_polls", 0)
+    again = dev.render_sums(cam, seed=3)
+    assert np.array_equal(again, good)
+    assert ctx.stats()["rays"] > 0
+    dev.close()
+
+
+def test_no_sample_is_dropped_or_clamped_on_ordinary_frames(ctx):
+    """rt_stats.samples_nan / samples_clamped count the radiance channels that did not reach the frame as computed (NaN
+    -> 0, > 2^20 -> 2^20).  Zero on the shipped scenes, lights included; non-zero when a light of 4e6 is looked at."""
+    for name, spp in (("book_cover", 16), ("cornell_smoke", 16)):
+        g = ra.Scene(name, 160, 16 / 9, "uniform", spp, 50)
+        dev = ra.DeviceScene(ctx, C.byref(g.desc))
+        sums = dev.render_sums(g.camera_copy(), seed=9)
+        st = ctx.stats()
+        assert np.isfinite(sums).all()
+        assert st["samples_nan"] == 0 and st["samples_clamped"] == 0, (name, st["samples_nan"], st["samples_clamped"])
+        dev.close()
+    # a sphere that emits 4e6: every path that sees it directly is clamped to 2^20 per channel, and counted
+    desc, keep = one_sphere(3, n_textures=1, tex_fields=dict(kind=0))
+    for a in range(3):
+        keep[2][0].rgb[a] = 4.0e6
+    keep[1][0].tex = 0
+    dev = ra.DeviceScene(ctx, desc)
+    cam = camera()
+    cam.background_mode = 1
+    sums = dev.render_sums(cam, seed=1)
+    st = ctx.stats()
+    assert st["samples_clamped"] > 0 and st["samples_nan"] == 0
+    assert sums.max() <= 16 * 1048576.0 * (1 + 1e-6)  # 16 spp, each clamped to 2^20
+    # sums of K clamped samples cannot overflow the fixed-point slot, whatever K: 4096 spp of the same view
+    cam.sampler_n = 64
+    big = dev.render_sums(cam, seed=1)
+    assert np.isfinite(big).all() and big.max() <= 4096 * 1048576.0 * (1 + 1e-6) and big.max() > 1e9
+    dev.close()

@@ -94,3 +94,36 @@ def test_progressive_argument_errors(ctx):
         g.render_progressive(ctx, passes=5)
     with pytest.raises(RuntimeError, match="passes must be in 1"):
         g.render_progressive(ctx, passes=0)
+
+
+def test_ten_thousand_samples_per_pixel_in_one_launch_and_in_slices(ctx, tmp_path):
+    """BASELINE config 5 is quoted at 10 000 spp (a 100 x 100 grid).  The bookkeeping that only such a K exercises — a
+    tile's path count `rem = n_valid * K` (640 000), the fixed-point format chosen from K (2^-29 at K = 10 000, 2^-31 at
+    2500), 32-bit sample arithmetic, chunks of a 10 000-deep tile — on a small frame of the final scene's types (lights,
+    media, glass, image and noise textures): ONE launch of all 10 000 sample indices equals the sum of four stride-4
+    slices of 2500 (a path depends only on (seed, pixel, sample index)), up to f32 rounding of the four partial sums and
+    the slices' finer fixed-point grid; and the checkpointed progressive form arrives at the same frame."""
+    from golden_data import load_earth_rgba
+    g = ra.Scene("final_scene_small", 64, ASPECT, "uniform", 10000, 50, texels=load_earth_rgba())
+    assert g.spp == 10000 and g.camera.sampler_n == 100
+    dev = g.upload(ctx)
+    cam = g.camera_copy()
+    whole = dev.render_sums(cam, seed=21)
+    st = ctx.stats()
+    assert st["paths"] == g.width * g.height * 10000 and st["samples_nan"] == 0 and st["samples_clamped"] == 0
+    parts = [dev.render_sums(cam, seed=21, sample_begin=r, sample_stride=4) for r in range(4)]
+    assert ctx.stats()["paths"] == g.width * g.height * 2500
+    total = np.sum(np.stack(parts).astype(np.float64), axis=0)
+    assert whole.max() > 100.0  # thousands of samples really were added up
+    # 10 000 truncations of at most 2^-29 each + f32 rounding of sums of magnitude <= ~1e5
+    assert np.allclose(whole, total, rtol=3e-7, atol=10000 * 2.0 ** -29 + 1e-6)
+    # two launches of the same sample set are identical bit for bit (integer sums)
+    assert np.array_equal(dev.render_sums(cam, seed=21, sample_begin=1, sample_stride=4), parts[1])
+    # checkpointed passes of 2500 (Camera::render_progressive) resolve to the single-shot frame
+    ref = ra.resolve(ctx, whole, 10000)
+    ck = str(tmp_path / "k10000.ckpt")
+    frame, rendered, _ = g.render_progressive(ctx, passes=4, seed=21, checkpoint_path=ck)
+    assert rendered == 4 and np.allclose(frame, ref, rtol=0, atol=2e-6)
+    frame, rendered, _ = g.render_progressive(ctx, passes=4, seed=21, checkpoint_path=ck)
+    assert rendered == 0 and np.allclose(frame, ref, rtol=0, atol=2e-6)
+    dev.close()

@@ -21,7 +21,7 @@ def test_abi_header_symbols_all_exported():
     lib = ra.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rt_abi_version() == 1
+    assert lib.rt_abi_version() == 2
 
 
 def test_abi_struct_sizes_match_header_layout():

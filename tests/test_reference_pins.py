@@ -6,7 +6,7 @@ reference's authors committed, compared at their NATIVE resolution through tests
      fraction of a pixel of the same curve in ours, and the other way round.  Pins all 484 sphere centres and radii of
      book_cover (scene.rs:114-143, i.e. the scene RNG stream), the camera basis and viewport (builder.rs:74-135), the
      checker's inv_scale and parity (texture.rs:50-60), the sphere uv mapping and the earth's orientation
-     (hittable/sphere.rs:37-46, texture.rs:84-101) to a pixel.  Measured (oracle, 16 spp): mean 0.12-0.31 px.
+     (hittable/geometry.rs:30-34, texture.rs:79-93) to a pixel.  Measured (oracle, 16 spp): mean 0.12-0.31 px.
  (b) per-object mean colour inside regions eroded by 3 px: pins the material / albedo / fuzz draw ORDER of
      scene.rs:114-143 (115 visible spheres; a permutation of the draws moves the median error from 0.003 to 0.27).
 

@@ -41,12 +41,23 @@ def test_noalloc_entry_matches_allocating_entry_twice_second_smaller():
         assert ref_big.min() >= 0 and ref_big.std() > 0 and ref_small.std() > 0
         torch.cuda.synchronize()
         free0 = torch.cuda.mem_get_info()[0]
+        # the checkable signal: the library counts every hipMalloc / hipFree / stream / event creation it makes, in any
+        # context of the process (rt_stats.lib_alloc_calls); the count must not move across the no-alloc calls
+        calls0 = ctx.stats()["lib_alloc_calls"]
+        assert calls0 > 0  # rt_init and the uploads allocated
         got_big = _render(dev_big, cam_big, big.width, big.height, 11, True)
         rays_big = ctx.stats()["rays"]
         got_small = _render(dev_small, cam_small, small.width, small.height, 12, True)
         got_part = _render(dev_small, cam_small, small.width, small.height, 12, True, sample_begin=1, sample_stride=3)
+        assert ctx.stats()["lib_alloc_calls"] == calls0, "rt_render_device_noalloc allocated or created a runtime object"
         # (torch's caching allocator serves the output tensors from its pool: device memory in use must not have grown)
         assert torch.cuda.mem_get_info()[0] >= free0
+        # ... and the counter does see an allocating path: the first feedback-ordered frame of the allocating entry point
+        # allocates its tile lists
+        _render(dev_big, cam_big, big.width, big.height, 11, False)
+        ctx2 = ra.Context(0)
+        assert ctx.stats()["lib_alloc_calls"] > calls0
+        ctx2.close()
         assert np.array_equal(got_big, ref_big)
         assert np.array_equal(got_small, ref_small)
         assert np.array_equal(got_part, ref_part)
