@@ -61,6 +61,9 @@ WORKLOADS = {
     "c5_full": ("final_scene", 3840, "uniform", 10000, 50, "workload_c5.json", 10000),
 }
 C5_FULL_PASSES = 10
+# flops of one merged-box test (aabox_hit: six quads of an axis-aligned box as one slab test): 6 sub + 6 mul + 4 min/max +
+# 1 compare + the face's division and range test, on the scale of SURVEY §8(d)'s F_box = 18
+F_AABOX = 20
 # integer work the flop count leaves out (reported separately): the noise texture's lattice hash
 NOISE_INT_OPS_REFERENCE = 8 * (128 * 8 + 64)   # texture.rs:148-162 as written: 8 corners x (128 xoroshiro steps + jump XORs)
 NOISE_INT_OPS_GPU = 40 * 6 + 8 * 12            # 40 GF(2) table lookups (load + 4 xor each) + 8 x (add, convert)
@@ -117,7 +120,8 @@ def own_tree_flops(wl, own):
     p, F = wl["per_sample"], wl["flop_constants"]
     sph = own["sphere_tests"] + own["moving_tests"]
     tree = (F["ray"] * own["rays"] + F["box"] * own["box_tests"] + F["sph"] * sph + F["mov"] * own["moving_tests"] +
-            F["sph_root"] * min(p["sphere_disc_pos"], sph) + F["quad"] * own["quad_tests"] + F["medium"] * own["medium_tests"])
+            F["sph_root"] * min(p["sphere_disc_pos"], sph) + F["quad"] * own["quad_tests"] + F["medium"] * own["medium_tests"] +
+            F_AABOX * own.get("aabox_tests", 0.0))
     shared = (F["cam"] + F["hit"] * p["bounce_hits"] + F["lam"] * p["scat_lambert"] + F["met"] * p["scat_metal"] +
               F["die"] * p["scat_dielectric"] + F["iso"] * p["scat_isotropic"] + F["tex_chk"] * p["tex_checker"] +
               F["tex_img"] * p["tex_image"] + F["tex_noise"] * p["tex_noise"] + F["mul"] * p["bounce_hits"] + F["sky"] * p["misses"])
@@ -139,12 +143,12 @@ def measure_own_tree(ctx, rig, stream, d_ptr, spp_slice=None):
         ctx.set_option("fused_stats", 0)
     n = max(st["paths"], 1)
     c = st["dbg_counts"]
-    if c[0] == 0 and c[1] + c[2] + c[3] + c[4] == 0:
+    if c[0] == 0 and c[1] + c[2] + c[3] + c[4] + c[5] == 0:
         return None  # this instance has no instrumented build
     return {"rays": st["rays"] / n, "box_tests": c[0] / n, "sphere_tests": c[1] / n, "moving_tests": c[2] / n,
-            "quad_tests": c[3] / n, "medium_tests": c[4] / n,
-            "node_loop_lane_slots": {"walking": st["dbg"][0], "at_leaf": c[5],
-                                     "finished": c[6], "no_path": c[7]}}
+            "quad_tests": c[3] / n, "medium_tests": c[4] / n, "aabox_tests": c[5] / n,
+            "node_loop_lane_slots": {"walking": st["dbg"][0], "at_leaf": c[6],
+                                     "finished": c[7], "no_path": c[8]}}
 
 
 def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats, own=None, frame_samples=None):

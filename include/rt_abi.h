@@ -164,9 +164,10 @@ typedef struct rt_stats {
    * (tests/test_gpu_parity.py); a caller that sees them non-zero knows that the frame dropped energy. */
   uint64_t samples_nan;     /* radiance channels that were NaN (added as 0) */
   uint64_t samples_clamped; /* radiance channels above 2^20 (added as 2^20) */
-  uint64_t dbg_counts[8];   /* "fused_stats" build, exact: [0] child boxes tested (node steps x 2; x 4 on the four-wide tree), [1..4] primitive tests by type (static sphere,
-                             * moving sphere, quad, medium; tree leaves + primitives kept outside the tree), [5..7] node-loop
-                             * trips a lane sat out waiting at a leaf / finished / without a path */
+  uint64_t dbg_counts[12];  /* "fused_stats" build, exact: [0] child boxes tested (node steps x 2; x 4 on the four-wide tree),
+                             * [1..5] primitive tests by type (static sphere, moving sphere, quad, medium, merged axis-aligned
+                             * box; tree leaves + primitives kept outside the tree), [6..8] node-loop trips a lane sat out
+                             * waiting at a leaf / finished / without a path */
   uint64_t lib_alloc_calls; /* hipMalloc / hipFree / stream / event creations this library has made in this process since
                              * it was loaded (all contexts): unchanged across a call <=> that call allocated nothing */
 } rt_stats;
@@ -251,7 +252,10 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * that do not fit LDS: 1 = four-wide tree / its binary16 form with the top levels cached in LDS, defaults; 0 = the
  * binary tree / f32 planes, kept as cross-checks), "fused_tail4" / "fused_tail2" (height, in per mille of the frame's rows, of the bands of 4x4 / 2x2 tiles at the
  * end of the tile list that keep the frame's tail short; 50 / 30; never changes the frame), "fused_slots" (tiles a workgroup keeps in flight,
- * 0 = auto), "fused_partner_min" (partner workgroups from this many Mi samples per frame), "global_prims" (1 = default, read by rt_scene_upload: spheres and spherical media whose box is a quarter of the scene's are kept out of
+ * 0 = auto), "fused_partner_min" (partner workgroups from this many Mi samples per frame), "merge_boxes" (1 = default, read by
+ * rt_scene_upload: six consecutive quads of one material that are the faces of an axis-aligned box enter the tree as ONE
+ * primitive; a hit still reports the face's quad and the same t), "dbg_watchdog_polls" (diagnostic: polls before a wave with
+ * nothing to do gives up, 0 = 2^24), "global_prims" (1 = default, read by rt_scene_upload: spheres and spherical media whose box is a quarter of the scene's are kept out of
  * the tree and tested first by every ray, and scenes of at most 8 primitives get no tree at all; hits unchanged, frames unchanged unless the primitive is a medium, whose
  * free-path draw then comes first in the ray's random stream), "fused_kr_sync" (regeneration threshold of the bounce-synchronous schedule, 1..64, default 8), "fused_feedback" (1 = default: a frame of
  * the same scene and camera as the last one hands out first the tiles whose paths went deepest then; frames unchanged), "fused_partner" (1 = default: sphere scenes resident in LDS get a second, 256-thread

@@ -86,7 +86,7 @@ pub struct rt_stats {
     pub ms_total: f32, pub ms_generate: f32, pub ms_intersect: f32, pub ms_shade: f32, pub ms_accumulate: f32,
     pub intersect_launches: u64, pub probe_rays: u64, pub probe_node_visits: u64, pub probe_prim_tests: u64,
     pub dbg: [f32; 16],
-    pub samples_nan: u64, pub samples_clamped: u64, pub dbg_counts: [u64; 8], pub lib_alloc_calls: u64,
+    pub samples_nan: u64, pub samples_clamped: u64, pub dbg_counts: [u64; 12], pub lib_alloc_calls: u64,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]

@@ -70,7 +70,7 @@ class RtStats(C.Structure):
                 ("ms_total", C.c_float), ("ms_generate", C.c_float), ("ms_intersect", C.c_float),
                 ("ms_shade", C.c_float), ("ms_accumulate", C.c_float), ("intersect_launches", C.c_uint64),
                 ("probe_rays", C.c_uint64), ("probe_node_visits", C.c_uint64), ("probe_prim_tests", C.c_uint64),
-                ("dbg", C.c_float * 16), ("samples_nan", C.c_uint64), ("samples_clamped", C.c_uint64), ("dbg_counts", C.c_uint64 * 8),
+                ("dbg", C.c_float * 16), ("samples_nan", C.c_uint64), ("samples_clamped", C.c_uint64), ("dbg_counts", C.c_uint64 * 12),
                 ("lib_alloc_calls", C.c_uint64)]
 
 

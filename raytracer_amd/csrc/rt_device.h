@@ -34,8 +34,10 @@ struct __attribute__((aligned(64))) BvhNode {  // 64 B: both child boxes + child
 struct __attribute__((aligned(128))) Prim {  // 128 B
   // SPHERE / MOVING_SPHERE: f[0..2]=center0, f[3..5]=center1, f[6]=radius
   // QUAD: f[0..2]=Q, f[3..5]=u, f[6..8]=v, f[9..11]=unit normal, f[12]=D, f[13]=1/|u x v|
-  // MEDIUM_SPHERE: f[0..2]=center, f[6]=radius, f[12]=-1/density
+  // MEDIUM_SPHERE: f[0..2]=center, f[3]=f[12]=-1/density, f[6]=radius
   // MEDIUM_BOX: f[0..2]=corner, f[3..5],f[6..8],f[9..11]=edges / |edge|^2, f[12]=-1/density
+  // AABOX (type 5, library-internal: six QUADs that form an axis-aligned box, merged at upload): f[0..2]=lo, f[3..5]=hi,
+  //        f[6..8] reinterpreted as int32 face[6] = primitive index of the quad on face 2*axis + (0: lo plane, 1: hi plane)
   double f[14];
   uint32_t type, mat;
   int32_t obj;
@@ -114,7 +116,13 @@ struct Hits {
 #define RT_F_TEX_NOISE 4u
 #define RT_F_QUAD 8u
 #define RT_F_MEDIUM 16u
-#define RT_F_ALL 31u
+#define RT_F_BOX 32u  // merged axis-aligned boxes (RT_PRIM_AABOX records) are present
+#define RT_F_ALL 63u
+#define RT_F_ALL_NOBOX 31u  // everything but merged boxes: the instance of general scenes that have none
+#define RT_PRIM_AABOX 5u
+#ifndef RT_AABOX_INLINE
+#define RT_AABOX_INLINE __device__ __forceinline__
+#endif
 #define RT_F_TEX_ANY 7u
 
 // ----------------------------------------------------------------------------------------------- RNG
@@ -453,7 +461,7 @@ struct TravCounters {
   uint32_t nodes, prims;  // per-lane node steps / leaf tests
   float wnodes, wprims;   // per-lane share of the wave's loop trips (sums to one per executed trip)
   float t_nodes, t_prims; // per-lane share of the wave's cycles in the inner-node loop / leaf section
-  uint32_t t_sph, t_mov, t_quad, t_med;      // leaf tests by primitive type (static sphere, moving sphere, quad, medium)
+  uint32_t t_sph, t_mov, t_quad, t_med, t_box;  // leaf tests by primitive type (static sphere, moving sphere, quad, medium, merged box)
   uint32_t idle_leaf, idle_done, idle_free;  // node-loop trips this lane sat out: waiting at a leaf / finished, waiting for shading / without a path
 };
 __device__ __forceinline__ uint64_t now_cycles() { return __builtin_readcyclecounter(); }
@@ -517,6 +525,55 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
   if (ab) { ab[0] = alpha; ab[1] = beta; }
   return true;
 }
+// Six quads that form an axis-aligned box, tested as ONE primitive (rt_scene_upload merges them; the quads stay in the
+// primitive table and a hit reports the quad of the face that was hit, so shading, uv and object ids are the quad's).
+// For an axis-aligned quad quad_hit's t is exactly (plane - o[a]) / d[a]: the unit normal is (+-1, 0, 0) up to order, so
+// n.o, n.d and D are single components and the zero terms add exactly — the division below is that same division, and `t`
+// is bit-identical to what the face's quad_hit returns.  WHICH face (and whether any) is decided by the slab test — entry
+// = latest near plane, exit = earliest far plane, hit iff entry <= exit — on reciprocals good to ~1e-14 instead of by the
+// six (alpha, beta) range tests: the two agree except within rounding of an edge, where the quads' own tests tie.  Faces of
+// an axis with |d[a]| < 1e-8 cannot be hit (quad_hit's parallel rejection).  Candidates like the quads': the entry face if
+// its t is inside (tmin, tmax), else the exit face (ray starts inside the box).
+RT_AABOX_INLINE bool aabox_hit(const Prim& P, d3 blo, d3 bhi, d3 o, d3 d, const SlabRay& s, double tmin, double tmax, double& t_out,
+                                          int32_t& face_prim) {
+  const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  const double lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
+  const float r32[3] = {s.mx.x, s.my.x, s.mz.x};  // f32 reciprocals of the direction (make_slab)
+  double te = -__builtin_inf(), tx = __builtin_inf();
+  int fe = 0, fx = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const double lo = lo3[a], hi = hi3[a];
+    if (__builtin_fabs(dd[a]) < 1e-8) {
+      if (oo[a] < lo || oo[a] > hi) return false;
+    } else {
+      double r = (double)r32[a];
+      r = __builtin_fma(__builtin_fma(-dd[a], r, 1.0), r, r);  // one Newton step: ~1e-14 relative
+      const bool neg = dd[a] < 0.;
+      const double tn = ((neg ? hi : lo) - oo[a]) * r, tf = ((neg ? lo : hi) - oo[a]) * r;
+      if (tn > te) { te = tn; fe = 2 * a + (neg ? 1 : 0); }
+      if (tf < tx) { tx = tf; fx = 2 * a + (neg ? 0 : 1); }
+    }
+  }
+  if (!(te <= tx) || te == -__builtin_inf()) return false;  // (te = -inf: every axis parallel — a degenerate direction)
+  // exact t of the chosen face: the entry face unless it is not beyond tmin, then the exit face
+  int f = fe;
+  double t = 0.;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    const int a = f >> 1;
+    const double plane = (f & 1) ? (a == 0 ? bhi.x : a == 1 ? bhi.y : bhi.z) : (a == 0 ? blo.x : a == 1 ? blo.y : blo.z);
+    const double oa = a == 0 ? o.x : a == 1 ? o.y : o.z, da = a == 0 ? d.x : a == 1 ? d.y : d.z;
+    t = (plane - oa) / da;
+    if (tmin < t) break;
+    f = fx;
+  }
+  if (!(tmin < t && t < tmax)) return false;
+  t_out = t;
+  // face[f]: int32 number f of the six packed into f[6..8] (read from the record only now: hits are the minority)
+  face_prim = reinterpret_cast<const int32_t*>(&P.f[6])[f];
+  return true;
+}
 #pragma clang fp contract(on)
 
 // EXT constant-density medium with a convex boundary (SURVEY aX3, "The Next Week" §9 in the reference's
@@ -526,6 +583,8 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
 __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, double inv_a, double tmin, double tmax,
                                            PathRng& rng, double& t_out) {
   double t1, t2;
+  // -1/density: f[12]; a spherical medium also carries it in f[3], inside the first 64 bytes of its record
+  const double neg_inv_density = P.type == 3u ? P.f[3] : P.f[12];
   if (P.type == 3u) {
     d3 oc = {o.x - P.f[0], o.y - P.f[1], o.z - P.f[2]};
     double hb = dot(oc, d);
@@ -562,7 +621,7 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
   double len = __builtin_sqrt(a);
   double dist_inside = (t2 - t1) * len;
   // free path -ln(u)/density: u is a 32-bit draw, so the hardware f32 logarithm (v_log_f32, ~1 ulp) loses nothing
-  double hit_distance = P.f[12] * (double)(__builtin_amdgcn_logf(u01f(rng_next(rng))) * 0.69314718056f);
+  double hit_distance = neg_inv_density * (double)(__builtin_amdgcn_logf(u01f(rng_next(rng))) * 0.69314718056f);
   if (hit_distance > dist_inside) return false;
   t_out = t1 + hit_distance * (len * inv_a);  // / len
   return true;
@@ -707,7 +766,7 @@ __device__ __forceinline__ void prim_test(const Acc& acc, TravState& ts, int32_t
   if (Acc::kSpheresOnly) {
     PrimGeom g = acc.sphere(pi);
     h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
-  } else if (Acc::kPrimsInHbm) {
+  } else if (Acc::kPrimsInHbm && !(features & RT_F_BOX)) {
     // one round trip: fetch the whole 128-B record (one cache line) before looking at its type, instead of
     // type -> branch -> fields (two dependent L1/L2 latencies per leaf on a latency-bound instance)
     const Prim P = acc.full(pi);
@@ -720,6 +779,25 @@ __device__ __forceinline__ void prim_test(const Acc& acc, TravState& ts, int32_t
     } else if ((features & RT_F_MEDIUM) && ty >= 3u) {
       h = medium_hit(P, o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t);
     }
+  } else if (Acc::kPrimsInHbm) {
+    // Scenes with merged boxes (their quads are few): one round trip for the common types — the first 56 bytes of the
+    // record (sphere: centres + radius; merged box: both corners; spherical medium: centre, -1/density, radius) and its
+    // (type, material) word are requested together, before the type is looked at.  Quads and box media read the rest of
+    // their record inside their branch.  (All 128 bytes up front hold 32 registers through every leaf test; with the
+    // merged-box code that tipped the final-scene instance into spilling inside the traversal loop: 46 -> 96 ms.)
+    const Prim& R = acc.full(pi);
+    const double f0 = R.f[0], f1 = R.f[1], f2 = R.f[2], f3 = R.f[3], f4 = R.f[4], f5 = R.f[5], f6 = R.f[6];
+    const uint32_t ty = R.type, mat = R.mat;
+    if (ty <= 1u) {
+      PrimGeom g = {{f0, f1, f2}, {f3, f4, f5}, f6, ty, mat};
+      h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
+    } else if ((features & RT_F_QUAD) && ty == 2u) {
+      h = quad_hit(R, o, d, tmin, ts.best_t, t);
+    } else if ((features & RT_F_BOX) && ty == RT_PRIM_AABOX) {
+      h = aabox_hit(R, d3{f0, f1, f2}, d3{f3, f4, f5}, o, d, ts.s, tmin, ts.best_t, t, pi);
+    } else if ((features & RT_F_MEDIUM) && ty >= 3u) {
+      h = medium_hit(R, o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t);
+    }
   } else {
     uint32_t ty = acc.type(pi);
     if (ty <= 1u) {
@@ -727,6 +805,9 @@ __device__ __forceinline__ void prim_test(const Acc& acc, TravState& ts, int32_t
       h = sphere_hit(g, o, d, ts.a, ts.inv_a, time, tmin, ts.best_t, t);
     } else if ((features & RT_F_QUAD) && ty == 2u) {
       h = quad_hit(acc.full(pi), o, d, tmin, ts.best_t, t);
+    } else if ((features & RT_F_BOX) && ty == RT_PRIM_AABOX) {
+      const Prim& R = acc.full(pi);
+      h = aabox_hit(R, d3{R.f[0], R.f[1], R.f[2]}, d3{R.f[3], R.f[4], R.f[5]}, o, d, ts.s, tmin, ts.best_t, t, pi);
     } else if ((features & RT_F_MEDIUM) && ty >= 3u) {
       h = medium_hit(acc.full(pi), o, d, ts.a, ts.inv_a, tmin, ts.best_t, rng, t);
     }
@@ -765,7 +846,7 @@ __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPr
 template <class Acc>
 __device__ __forceinline__ void count_leaf_type(const Acc& acc, int32_t pi, TravCounters* cnt) {
   const uint32_t ty = acc.type(pi);
-  cnt->t_sph += ty == 0u; cnt->t_mov += ty == 1u; cnt->t_quad += ty == 2u; cnt->t_med += ty >= 3u;
+  cnt->t_sph += ty == 0u; cnt->t_mov += ty == 1u; cnt->t_quad += ty == 2u; cnt->t_med += ty == 3u || ty == 4u; cnt->t_box += ty == RT_PRIM_AABOX;
 }
 
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short

@@ -316,6 +316,10 @@ static_assert(sizeof(WgSched) % 16 == 0, "scheduler block keeps the LDS regions 
 #define RT_CUR_EXHAUSTED 0xFFFFFFFFu
 #define RT_FIX_CLAMP 1048576.0f  // 2^20: largest radiance channel a sample can add
 
+// workgroup size of the HBM-resident instances that carry the whole feature set (noise / image / medium code)
+#ifndef RT_HEAVY_BLOCK
+#define RT_HEAVY_BLOCK 768
+#endif
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5,
        KIND_GENERIC_WIDE_HALF = 6, KIND_SPHERES_WIDE_HALF = 7 };
 constexpr bool kind_caches_top(int k) { return k == KIND_GENERIC_WIDE_HALF || k == KIND_SPHERES_WIDE_HALF; }
@@ -456,7 +460,7 @@ template <> struct AccOf<KIND_SPHERES_WIDE> {
 // The lean spheres-in-LDS instance and its 256-thread partner share a CU (4 + 1 waves per SIMD): the partner is held to
 // the 5-waves budget (96 VGPRs), the main instance to 104 (fused_max_vgprs).
 constexpr int fused_waves_per_simd(uint32_t F, int KIND, int BLOCK) {
-  if (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_TEX_NOISE))) return 3;
+  if (BLOCK == 768 || (BLOCK == 256 && (F & RT_F_TEX_NOISE))) return 3;  // (RT_HEAVY_BLOCK 1024: 4 waves, 128 VGPRs)
   if (F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_WIDE_HALF && BLOCK == 256) return 5;
   return 4;
 }
@@ -500,7 +504,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   // The camera block (26 doubles) stays in memory: read with scalar loads where a ray is generated instead of
   // occupying ~60 SGPRs for the whole kernel (they spilled to VGPR lanes: 68 v_readlane per regeneration).
   struct { uint32_t width, height, max_depth; } cam = {camp->width, camp->height, camp->max_depth};
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0, 0};
   float st_regen = 0.f, st_wregen = 0.f, st_shade = 0.f, st_wshade = 0.f, st_tshade = 0.f, st_tregen = 0.f, st_ttotal = 0.f;
   uint64_t st_t0 = 0, st_tk = 0;
   float st_twait = 0.f;                  // cycles in the "nothing to hand out" polling loop
@@ -805,8 +809,8 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       // [4..6] node-loop trips sat out by reason, [7] child boxes tested (node steps x 2, or x 4 on the four-wide tree),
       // [8..11] leaf tests by primitive type (exact counts)
       constexpr unsigned long long kBoxes = AccOf<KIND>::type::kWide ? 4ull : 2ull;
-      unsigned long long v8[8] = {tc.idle_leaf, tc.idle_done, tc.idle_free, tc.nodes * kBoxes, tc.t_sph, tc.t_mov, tc.t_quad, tc.t_med};
-      for (int k = 0; k < 8; k++) {
+      unsigned long long v8[9] = {tc.idle_leaf, tc.idle_done, tc.idle_free, tc.nodes * kBoxes, tc.t_sph, tc.t_mov, tc.t_quad, tc.t_med, tc.t_box};
+      for (int k = 0; k < 9; k++) {
         unsigned long long x = v8[k];
         for (int off2 = 32; off2 > 0; off2 >>= 1) x += __shfl_down(x, off2, 64);
         if (lane == 0 && x) atomicAdd(&fp.timeline[4 + k], x);
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
   __shared__ uint32_t stack_rows[(RT_STACK_DEPTH + 1) * RT_BLOCK];  // row 0: guard row below the columns (trav_pop)
   uint32_t* const stack = stack_rows + RT_BLOCK;
   const uint32_t stride = gridDim.x * blockDim.x;
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     rt_ray r = rays[i];
     d3 o = {r.o[0], r.o[1], r.o[2]}, d = {r.d[0], r.d[1], r.d[2]};
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
   const uint32_t per = (n + n_waves - 1) / n_waves;
   uint32_t next = min(n, wave * per);
   const uint32_t total = min(n, next + per);
-  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0};
+  TravCounters tc = {0, 0, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0, 0, 0, 0};
   bool active = false, fresh_lane = false, fresh = false;
   uint32_t ray_index = 0;
   d3 o = {0, 0, 0}, d = {0, 0, 0};
@@ -1049,7 +1053,7 @@ struct rt_scene {
   int bvh_depth = 0;
   uint64_t serial = 0;       // unique per upload (tile-order feedback recognises "the same scene" by it)
   uint32_t features = 0;     // RT_F_* of what the scene contains
-  uint32_t global_types[4] = {0, 0, 0, 0};  // primitives on the global list by type (static sphere, moving sphere, quad, medium)
+  uint32_t global_types[5] = {0, 0, 0, 0, 0};  // primitives on the global list by type (static sphere, moving sphere, quad, medium, merged box)
   bool spheres_only = false;
 };
 
@@ -1112,10 +1116,11 @@ struct rt_ctx {
   // order built from them, and what that frame looked at
   unsigned long long* d_timeline = nullptr;  // instrumented build (FusedParams::timeline)
   int fused_kr_sync = 8;  // regeneration threshold of the bounce-synchronous schedule (small scenes)
+  int merge_boxes = 1;   // scene upload: six quads that form an axis-aligned box become one RT_PRIM_AABOX in the tree
   int global_prims = 1;  // scene upload: keep huge spheres out of the tree and test them first (Scene::n_global)
   int fused_feedback = 1;
   hipStream_t fb_stream = nullptr;  // stream of the frame that recorded d_tile_class (feedback is only ordered through it)
-  uint32_t last_global_types[4] = {0, 0, 0, 0};  // global primitives of the last instrumented render's scene, by type
+  uint32_t last_global_types[5] = {0, 0, 0, 0, 0};  // global primitives of the last instrumented render's scene, by type
   int dbg_watchdog_polls = 0;       // diagnostic: polls before a wave with nothing to do gives up (0 = 2^24)
   unsigned char* d_tile_class = nullptr;
   uint32_t* d_tile_order = nullptr;
@@ -1363,6 +1368,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "fused_kr_sync") {
     if (value < 1 || value > 64) return fail(ctx, RT_E_INVALID_ARG, "fused_kr_sync must be in 1..64");
     ctx->fused_kr_sync = (int)value;
+  } else if (k == "merge_boxes") {
+    ctx->merge_boxes = value ? 1 : 0;  // (applies to scenes uploaded afterwards)
   } else if (k == "global_prims") {
     ctx->global_prims = value ? 1 : 0;  // (applies to scenes uploaded afterwards)
   } else if (k == "fused_feedback") {
@@ -1522,6 +1529,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
           b.hi[a] = p.a[a] + std::fabs(p.radius);
         }
         q.f[6] = p.radius;
+        q.f[3] = q.f[12];  // (inside the first 64 bytes of the record: prim_test's one-round-trip fetch)
       } else {
         if (!finite3(p.a) || !finite3(p.b) || !finite3(p.c) || !finite3(p.d))
           return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": non-finite medium box");
@@ -1544,45 +1552,110 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": unknown primitive type");
     }
   }
+  // Merged boxes (option merge_boxes): six consecutive quads of one material that are the six faces of an axis-aligned
+  // box — what the host's box() helper emits (raytracer.cpp; the book's box()) when no rotation is baked in — are tested
+  // as ONE primitive (RT_PRIM_AABOX, aabox_hit): one slab test and one division instead of up to six plane tests, one
+  // leaf instead of six in the tree (final scene: 3 409 -> 1 409 tree primitives).  The quads stay in the table — a hit
+  // reports the face's quad, so object ids, normals, uv and materials are untouched — and simply leave the tree.
+  const size_t n_orig = prims.size();
+  std::vector<char> in_group(n_orig, 0);
+  if (ctx->merge_boxes) {
+    for (size_t i = 0; i + 6 <= n_orig;) {
+      bool ok = true;
+      int32_t face[6] = {-1, -1, -1, -1, -1, -1};
+      double lo[3], hi[3];
+      for (int a = 0; a < 3; a++) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+      for (size_t k = i; k < i + 6 && ok; k++) {
+        ok = d->prims[k].type == RT_PRIM_QUAD && d->prims[k].material_id == d->prims[i].material_id;
+        if (ok)
+          for (int a = 0; a < 3; a++) {
+            const double c0 = d->prims[k].a[a], c1 = c0 + d->prims[k].b[a], c2 = c0 + d->prims[k].c[a], c3 = c1 + d->prims[k].c[a];
+            lo[a] = std::fmin(lo[a], std::fmin(std::fmin(c0, c1), std::fmin(c2, c3)));
+            hi[a] = std::fmax(hi[a], std::fmax(std::fmax(c0, c1), std::fmax(c2, c3)));
+          }
+      }
+      for (int a = 0; a < 3 && ok; a++) ok = hi[a] > lo[a];
+      for (size_t k = i; k < i + 6 && ok; k++) {
+        // u and v along two different axes, the quad lies in a face plane of [lo, hi] and spans that face exactly
+        const rt_prim& q = d->prims[k];
+        int au = -1, av = -1;
+        for (int a = 0; a < 3; a++) {
+          if (q.b[a] != 0.0) { if (au >= 0) ok = false; au = a; }
+          if (q.c[a] != 0.0) { if (av >= 0) ok = false; av = a; }
+        }
+        if (!ok || au < 0 || av < 0 || au == av) { ok = false; break; }
+        const int an = 3 - au - av;  // the axis of the normal
+        const double e[2][2] = {{std::fmin(q.a[au], q.a[au] + q.b[au]), std::fmax(q.a[au], q.a[au] + q.b[au])},
+                                {std::fmin(q.a[av], q.a[av] + q.c[av]), std::fmax(q.a[av], q.a[av] + q.c[av])}};
+        if (e[0][0] != lo[au] || e[0][1] != hi[au] || e[1][0] != lo[av] || e[1][1] != hi[av]) { ok = false; break; }
+        const int side = q.a[an] == lo[an] ? 0 : q.a[an] == hi[an] ? 1 : -1;
+        if (side < 0 || face[2 * an + side] >= 0) { ok = false; break; }
+        face[2 * an + side] = (int32_t)k;
+      }
+      if (!ok) { i++; continue; }
+      Prim b;
+      memset(&b, 0, sizeof(b));
+      b.type = RT_PRIM_AABOX;
+      b.mat = d->prims[i].material_id;
+      b.obj = d->prims[i].object_id;
+      for (int a = 0; a < 3; a++) { b.f[a] = lo[a]; b.f[3 + a] = hi[a]; }
+      memcpy(&b.f[6], face, sizeof(face));
+      rtb::Box bb;
+      for (int a = 0; a < 3; a++) { bb.lo[a] = lo[a]; bb.hi[a] = hi[a]; }
+      prims.push_back(b);
+      boxes.push_back(bb);
+      for (size_t k = i; k < i + 6; k++) in_group[k] = 1;
+      sc->features |= RT_F_BOX;
+      i += 6;
+    }
+  }
+  in_group.resize(prims.size(), 0);
+  // what rays are tested against: every primitive that is not a face of a merged box
+  std::vector<int32_t> cand;
+  for (size_t i = 0; i < prims.size(); i++)
+    if (!in_group[i]) cand.push_back((int32_t)i);
   // Global primitives (Scene::n_global): (moving) spheres whose box is at least a quarter of the scene's, at most two, in
   // scenes with a tree to speak of.  They stay in the primitive tables; the tree is built over the others.
   std::vector<int32_t> in_tree;
   int32_t globals[RT_MAX_GLOBAL] = {0, 0, 0, 0, 0, 0, 0, 0};
   int n_global = 0;
   // tiny scenes (the Cornell boxes: 8 primitives): no tree, every ray tests every primitive, uniformly across the wave
-  const bool tiny = ctx->global_prims && !boxes.empty() && boxes.size() <= RT_MAX_GLOBAL;
+  const bool tiny = ctx->global_prims && !cand.empty() && cand.size() <= RT_MAX_GLOBAL;
   if (tiny) {
-    for (size_t i = 0; i < boxes.size(); i++) globals[n_global++] = (int32_t)i;
-  } else if (ctx->global_prims && boxes.size() >= 32) {
-    rtb::Box all = boxes[0];
-    for (const rtb::Box& b : boxes)
-      for (int a = 0; a < 3; a++) { all.lo[a] = std::min(all.lo[a], b.lo[a]); all.hi[a] = std::max(all.hi[a], b.hi[a]); }
+    for (int32_t i : cand) globals[n_global++] = i;
+  } else if (ctx->global_prims && cand.size() >= 32) {
+    rtb::Box all = boxes[(size_t)cand[0]];
+    for (int32_t i : cand)
+      for (int a = 0; a < 3; a++) { all.lo[a] = std::min(all.lo[a], boxes[(size_t)i].lo[a]); all.hi[a] = std::max(all.hi[a], boxes[(size_t)i].hi[a]); }
     auto area = [](const rtb::Box& b) {
       const double x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
       return x * y + y * z + z * x;
     };
     const double whole = area(all);
-    for (size_t i = 0; i < boxes.size() && n_global < 2; i++)
-      if ((d->prims[i].type <= RT_PRIM_MOVING_SPHERE || d->prims[i].type == RT_PRIM_MEDIUM_SPHERE) && area(boxes[i]) >= 0.25 * whole)
+    for (size_t k = 0; k < cand.size() && n_global < 2; k++) {
+      const size_t i = (size_t)cand[k];
+      if ((prims[i].type <= RT_PRIM_MOVING_SPHERE || prims[i].type == RT_PRIM_MEDIUM_SPHERE) && area(boxes[i]) >= 0.25 * whole)
         globals[n_global++] = (int32_t)i;
+    }
   }
   std::vector<rtb::Box> tree_boxes;
-  if (n_global && !tiny) {
-    for (size_t i = 0; i < boxes.size(); i++)
-      if (!(n_global > 0 && (int32_t)i == globals[0]) && !(n_global > 1 && (int32_t)i == globals[1])) {
-        in_tree.push_back((int32_t)i);
-        tree_boxes.push_back(boxes[i]);
-      }
-  }
+  for (int32_t i : cand)
+    if (tiny || !((n_global > 0 && i == globals[0]) || (n_global > 1 && i == globals[1]))) {
+      in_tree.push_back(i);
+      tree_boxes.push_back(boxes[(size_t)i]);
+    }
   // (a tiny scene keeps its tree in memory — probe forms and sizes are unchanged — but no render or probe walks it)
-  rtb::BuildResult bvh = rtb::build_bvh(n_global && !tiny ? tree_boxes : boxes, RT_STACK_DEPTH);
-  if (n_global && !tiny) {  // leaf references back to positions in the primitive tables
+  rtb::BuildResult bvh = rtb::build_bvh(tree_boxes, RT_STACK_DEPTH);
+  {  // leaf references back to positions in the primitive tables
     auto fix = [&in_tree](int32_t& ref) { if (ref < 0 && ref != rtb::EMPTY_CHILD) ref = ~in_tree[(size_t)~ref]; };
     for (rtb::FlatNode& nd : bvh.nodes) { fix(nd.left); fix(nd.right); }
     fix(bvh.root);
   }
   sc->view.n_global = n_global;
-  for (int g = 0; g < n_global; g++) sc->global_types[std::min<uint32_t>(d->prims[globals[g]].type, 3u)]++;
+  for (int g = 0; g < n_global; g++) {
+    const uint32_t ty = prims[(size_t)globals[g]].type;
+    sc->global_types[ty <= 2u ? ty : ty == RT_PRIM_AABOX ? 4u : 3u]++;
+  }
   sc->view.tree_empty = tiny ? 1 : 0;
   HIP_TRY(ctx, rti::dev_malloc(&sc->d_global, RT_MAX_GLOBAL * sizeof(int32_t)));
   HIP_TRY(ctx, hipMemcpy(sc->d_global, globals, RT_MAX_GLOBAL * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -2136,7 +2209,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   fp.stack_depth = sdepth;
   fp.kb = (uint32_t)ctx->fused_kb; fp.kn = (uint32_t)ctx->fused_kn; fp.kr = use_resume(ctx, scene) ? (uint32_t)ctx->fused_kr : (uint32_t)ctx->fused_kr_sync;
   const bool lean = (scene->features & ~RT_F_TEX_CHECKER) == 0;
-  const uint32_t tex_only = scene->features & RT_F_TEX_ANY;  // texture kinds present (kernels are specialised on them)
+  // texture kinds present (kernels are specialised on them); merged boxes count as "more than the Cornell instance has"
+  const uint32_t tex_only = scene->features & (RT_F_TEX_ANY | RT_F_BOX);
   const bool small_ids = (int64_t)scene->view.n_nodes * (RT_SLAB_NODE_BYTES / 16) < 32768 && scene->view.n_prims < 32000;  // int16 stack entries
   int rc;
   // LDS budget of the 1024-thread spheres-in-LDS variant: scene + accumulators + u16 stack
@@ -2253,7 +2327,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_dbg, 0, 16 * sizeof(float), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline, 0xFF, sizeof(unsigned long long), st));     // [0]: minimum
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_timeline + 1, 0, 15 * sizeof(unsigned long long), st));
-    for (int k = 0; k < 4; k++) ctx->last_global_types[k] = scene->global_types[k];
+    for (int k = 0; k < 5; k++) ctx->last_global_types[k] = scene->global_types[k];
     fp.timeline = ctx->d_timeline;
   }
   if (scene->spheres_only && ctx->fused_lds && small_ids && lds_1024 <= 160 * 1024) {
@@ -2290,7 +2364,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     // scene's coordinates fit binary16 and its references the 16-bit stack.  768 threads (3 waves/SIMD, 168 VGPRs)
     // for the instances with the noise code, 1024 otherwise.
     const bool heavy = !(scene->spheres_only && lean);  // instances compiled with RT_F_TEX_NOISE
-    const uint32_t cblock = heavy ? 768u : 1024u;
+    const uint32_t cblock = heavy ? (uint32_t)RT_HEAVY_BLOCK : 1024u;
     // (slots before cache: 2 per wave + 8, if the stacks leave that much)
     const size_t cbase = RT_SCHED_BYTES + (size_t)sd * cblock * 2;
     const uint32_t cslots = cbase + 16 * 64 < 160 * 1024 ? fused_slots(ctx, 2 * (cblock / 64) + 8, 160 * 1024 - cbase - 16 * 64) : cblock / 64;
@@ -2301,11 +2375,12 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
       fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (160 * 1024 - cfixed) / 64);
       const size_t csmem = cfixed + (size_t)fp.n_cached * 64;
       if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 1024, int16_t>(ctx, scene, dc, fp, csmem, st);
-      else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_WIDE_HALF, 768, int16_t>(ctx, scene, dc, fp, csmem, st);
+      else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);
       else if (ctx->fused_stats) {
-        if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, 768, int16_t, true, true>(ctx, scene, dc, fp, csmem, st);
-        else rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, 768, int16_t, true, false>(ctx, scene, dc, fp, csmem, st);
-      } else rc = launch_variant<RT_F_ALL, KIND_GENERIC_WIDE_HALF, 768, int16_t>(ctx, scene, dc, fp, csmem, st);
+        if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t, true, true>(ctx, scene, dc, fp, csmem, st);
+        else rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t, true, false>(ctx, scene, dc, fp, csmem, st);
+      } else if (scene->features & RT_F_BOX) rc = launch_variant<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);
+      else rc = launch_variant<RT_F_ALL_NOBOX, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);
     } else if (wide) { RT_GLOBAL_DISPATCH(KIND_SPHERES_WIDE, KIND_GENERIC_WIDE) }
     else { RT_GLOBAL_DISPATCH(KIND_SPHERES_GLOBAL, KIND_GENERIC) }
 #undef RT_GLOBAL_DISPATCH
@@ -2429,8 +2504,8 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
       HIP_TRY(ctx, hipMemcpy(tl, ctx->d_timeline, sizeof(tl), hipMemcpyDeviceToHost));
       ctx->stats.dbg_counts[0] = tl[7];
       // leaf tests by type + the global primitives every ray tests before it enters the tree
-      for (int k = 0; k < 4; k++) ctx->stats.dbg_counts[1 + k] = tl[8 + k] + (uint64_t)ctx->last_global_types[k] * rays[0];
-      for (int k = 0; k < 3; k++) ctx->stats.dbg_counts[5 + k] = tl[4 + k];
+      for (int k = 0; k < 5; k++) ctx->stats.dbg_counts[1 + k] = tl[8 + k] + (uint64_t)ctx->last_global_types[k] * rays[0];
+      for (int k = 0; k < 3; k++) ctx->stats.dbg_counts[6 + k] = tl[4 + k];
     }
     if (ctx->fused_stats && getenv("RT_VERBOSE")) {
       unsigned long long tl[8];

@@ -242,3 +242,55 @@ def test_every_tree_form_returns_the_same_hits(ctx, name, width):
                 assert np.array_equal(h["n"][same], h0["n"][same]) and np.array_equal(h["p"][same], h0["p"][same])
         finally:
             ctx.set_option("probe_tree", 0)
+
+
+@pytest.mark.parametrize("name,width", [("final_scene_small", 200), ("final_scene", 200)])
+@pytest.mark.parametrize("form", [0, 4])
+def test_merged_boxes_return_the_quads_hits(ctx, name, width, form):
+    """rt_scene_upload merges six quads that form an axis-aligned box into one primitive of the tree (option merge_boxes,
+    default on; final scene: 3 409 -> 1 409 tree primitives).  A hit reports the quad of the face that was hit, and its t
+    is the same division the quad's own test performs: against the unmerged scene the object ids agree except on seams
+    between faces (equal t), t is BIT-IDENTICAL wherever the ids agree, and the frames estimate the same image."""
+    from golden_data import load_earth_rgba
+    tex = load_earth_rgba()
+    o = OracleScene(name, width, 1.0, "uniform", 1, 50, texels=tex)
+    g = ra.Scene(name, width, 1.0, "uniform", 16, 50, texels=tex)
+    rays = o.primary_rays(time=0.25)
+    # secondary-like rays too: from points on the ground boxes upwards and sideways (origins ON box faces)
+    rng = np.random.default_rng(5)
+    extra = rays[: len(rays) // 2].copy()
+    ho = o.intersect(rays)
+    sel = np.flatnonzero(ho["object_id"] >= 0)[: len(extra)]
+    extra = extra[: len(sel)]
+    extra["o"] = ho["p"][sel]
+    extra["d"] = rng.normal(size=(len(sel), 3))
+    allrays = np.concatenate([rays, extra])
+    hits = {}
+    for merge in (0, 1):
+        ctx.set_option("merge_boxes", merge)
+        ctx.set_option("probe_tree", form)
+        try:
+            dev = g.upload(ctx)
+            hits[merge] = dev.intersect(allrays)
+            if merge == 1:
+                frame_m = dev.render_sums(g.camera_copy(), seed=3)
+            else:
+                frame_q = dev.render_sums(g.camera_copy(), seed=3)
+            dev.close()
+        finally:
+            ctx.set_option("probe_tree", 0)
+            ctx.set_option("merge_boxes", 1)
+    a, b = hits[0], hits[1]
+    prims = g.prims()
+    medium_ids = list(set(prims["object_id"][prims["type"] >= 3].tolist()))
+    is_med = np.isin(a["object_id"], medium_ids) | np.isin(b["object_id"], medium_ids)  # media scatter at random
+    same = a["object_id"] == b["object_id"]
+    tie = ~same & (a["object_id"] >= 0) & (b["object_id"] >= 0) & (np.abs(a["t"] - b["t"]) <= 1e-9 * np.maximum(np.abs(a["t"]), 1.0))
+    bad = ~same & ~tie & ~is_med
+    assert bad.sum() <= 2e-5 * len(allrays), (int(bad.sum()), np.flatnonzero(bad)[:5])  # (rays through a box edge within rounding)
+    both = same & (a["object_id"] >= 0) & ~is_med
+    assert both.sum() > 0.3 * len(allrays)
+    assert np.array_equal(a["t"][both], b["t"][both])  # the same division
+    assert np.array_equal(a["n"][both], b["n"][both]) and np.array_equal(a["front_face"][both], b["front_face"][both])
+    # whole frames: different trees give the media's free-path draws a different order => statistical agreement
+    assert abs(frame_m.mean() - frame_q.mean()) <= 0.02 * frame_q.mean()
