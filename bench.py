@@ -374,6 +374,37 @@ def main():
         el_off = timed(step_strong, max(3, min(args.steps, 10)), 1)
         ctx.set_option("fused_feedback", 1)
         extra["ms_per_step_feedback_off"] = el_off / max(3, min(args.steps, 10)) * 1e3
+    # Batched frames (rt_render_batch_device): B successive frames of the config — this rank's slice of each — in ONE
+    # persistent launch, then B reduces and resolves: the per-frame drain of the deepest paths is paid once per batch
+    # instead of once per frame, which is what limits strong scaling of a 9 ms frame.  Secondary field;
+    # `value` stays the one-launch-per-frame figure (the reference renders one frame per call).
+    if args.workload in ("c1", "c2"):
+        B = 8
+        b_, e_, s_ = mg.sample_slice(rank, world, rig.spp)
+        # every frame of a batch must select the same number of sample indices: this rank's slice as it is
+        outs = [torch.zeros_like(d_sum) for _ in range(B)]
+        ptrs = [o.data_ptr() for o in outs]
+
+        def batch_step(i):
+            ra.render_batch_device(rig.dev, rig.cam, ptrs, [(seed0 + 1000 + i * B + k) & 0xFFFFFFFFFFFFFFFF for k in range(B)],
+                                   [b_] * B, sample_end=e_, sample_stride=s_, stream=stream)
+            for o in outs:
+                if world > 1 and args.rehearse:
+                    h = o.cpu()
+                    dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+                    o.copy_(h)
+                elif world > 1:
+                    dist.reduce(o, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    ctx.check(ctx.L.rt_resolve_device(ctx.h, o.data_ptr(), W, H, rig.spp, 2.2, None, d_u8.data_ptr(), stream))
+
+        nb = max(1, min(args.steps, 16) // 2)
+        elb = timed(batch_step, nb, 1)
+        extra["batched"] = {"frames_per_launch": B, "launches": nb, "ms_per_frame": elb / (nb * B) * 1e3,
+                            "value": frame_samples * nb * B / elb / 1e6, "unit": "Msamples/s",
+                            "note": "B frames per rt_render_batch_device launch + B reduces / resolves; frames bit-identical to "
+                                    "single launches (tests/test_gpu_batch.py)"}
+        del outs
     if world > 1:
         # (1) the N-rank frame is the one-rank frame: rank 0 renders the whole frame itself and compares
         step_strong(12345)

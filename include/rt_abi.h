@@ -230,6 +230,19 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
                              uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream);
 
+/* Several frames of ONE scene through ONE camera in a single persistent launch (animation frames / progressive passes /
+ * the per-GPU slices of successive frames of a multi-GPU job): frame i renders the sample indices {sample_begins[i] + k *
+ * sample_stride < sample_end} with key seeds[i] into d_out_sums[i] (device pointers, W*H*3 f32 each, may not overlap).
+ * Every frame must select the same non-zero number of sample indices (else RT_E_INVALID_ARG: split the batch).  Each
+ * frame is bit-identical to the rt_render_device frame of the same arguments; what changes is the time — the tile list is
+ * the frames' lists back to back, so the next frame's tiles are handed out while the deepest paths of the previous frame
+ * still bounce, and the per-frame drain (~0.4 ms at any spp) is paid once per batch.  Fused mode only; asynchronous on
+ * `hip_stream` (NULL = the ctx's stream) like rt_render_device; allocates (grow-only) the frame table.
+ * Replaces: successive calls of Camera::render (src/camera/mod.rs:54-58) on one world — no counterpart as one call. */
+int rt_render_batch_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t n_frames, const uint64_t* seeds,
+                           const uint32_t* sample_begins, uint32_t sample_end, uint32_t sample_stride, float* const* d_out_sums,
+                           void* hip_stream);
+
 /* mean = sum / spp, gamma correction powf(1/gamma) per channel, optional 8-bit quantisation
  * `(256.0 * x) as u8` (saturating, NaN -> 0).  Either output may be NULL.  Host pointers.
  * Replaces: `accumulator / n` (mod.rs:162,171), Color::gamma_corrected (src/color.rs:58-61, gamma 2.2 at

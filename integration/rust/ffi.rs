@@ -110,6 +110,9 @@ extern "C" {
     pub fn rt_render_device_noalloc(ctx: *mut rt_ctx, scene: *const rt_scene, cam: *const rt_camera, seed: u64,
                                     sample_begin: u32, sample_end: u32, sample_stride: u32, d_out_sum: *mut f32,
                                     hip_stream: *mut c_void) -> c_int;
+    pub fn rt_render_batch_device(ctx: *mut rt_ctx, scene: *const rt_scene, cam: *const rt_camera, n_frames: u32, seeds: *const u64,
+                                  sample_begins: *const u32, sample_end: u32, sample_stride: u32, d_out_sums: *const *mut f32,
+                                  hip_stream: *mut c_void) -> c_int;
     pub fn rt_resolve(ctx: *mut rt_ctx, sum: *const f32, width: u32, height: u32, spp: u32, gamma: f64,
                       out_rgb: *mut f64, out_rgb8: *mut u8) -> c_int;
     pub fn rt_resolve_device(ctx: *mut rt_ctx, d_sum: *const f32, width: u32, height: u32, spp: u32, gamma: f64,

@@ -21,7 +21,7 @@ RT_NOALLOC_MAX_PIXELS = 1 << 24  # include/rt_abi.h
 ABI_SYMBOLS = [
     "rt_abi_version", "rt_init", "rt_shutdown", "rt_last_error", "rt_scene_upload", "rt_scene_free", "rt_intersect",
     "rt_render", "rt_render_device", "rt_resolve", "rt_resolve_device", "rt_get_stats", "rt_set_option",
-    "rt_philox4x32_10", "rt_half_round_bits", "rt_synchronize", "rt_render_device_noalloc",
+    "rt_philox4x32_10", "rt_half_round_bits", "rt_synchronize", "rt_render_device_noalloc", "rt_render_batch_device",
     "rt_multi_init", "rt_multi_shutdown", "rt_multi_last_error", "rt_multi_device_count", "rt_multi_scene_upload",
     "rt_multi_render", "rt_multi_render_device", "rt_multi_set_option", "rt_multi_get_stats",
 ]
@@ -122,6 +122,9 @@ def lib():
         _gpu = L  # an older build loaded on purpose (A/B timing): only the entry points it has are bound
         return L
     L.rt_render_device_noalloc.argtypes = L.rt_render_device.argtypes
+    if hasattr(L, "rt_render_batch_device"):
+        L.rt_render_batch_device.argtypes = [vp, vp, C.POINTER(RtCamera), C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                             C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p), vp]
     L.rt_multi_init.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.rt_multi_shutdown.argtypes = [vp]
     L.rt_multi_last_error.argtypes = [vp]
@@ -268,6 +271,17 @@ class DeviceScene:
         fn = self.ctx.L.rt_render_device_noalloc if no_alloc else self.ctx.L.rt_render_device
         self.ctx.check(fn(self.ctx.h, self.h, C.byref(cam), seed, sample_begin, sample_end, sample_stride, d_out_ptr,
                           stream))
+
+
+def render_batch_device(dev_scene, cam, d_out_ptrs, seeds, sample_begins, sample_end=None, sample_stride=1, stream=None):
+    """rt_render_batch_device: len(d_out_ptrs) frames of one scene and camera in one persistent launch."""
+    n = len(d_out_ptrs)
+    if sample_end is None:
+        sample_end = cam.sampler_n * cam.sampler_n if cam.sampler_kind == 0 else cam.sampler_n
+    ctx = dev_scene.ctx
+    ctx.check(ctx.L.rt_render_batch_device(ctx.h, dev_scene.h, C.byref(cam), n, (C.c_uint64 * n)(*[s & 0xFFFFFFFFFFFFFFFF for s in seeds]),
+                                           (C.c_uint32 * n)(*sample_begins), sample_end, sample_stride,
+                                           (C.c_void_p * n)(*d_out_ptrs), stream))
 
 
 class MultiContext:

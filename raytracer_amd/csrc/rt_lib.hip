@@ -268,6 +268,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const float* __restrict
 // + prefix).  No path state ever touches HBM.
 #define RT_MAX_SLOTS 64
 #define RT_TILE_LEVELS 3
+struct BatchFrame {  // one frame of a batch (device table, read with scalar loads)
+  uint32_t k0, k1;   // Philox key (seed)
+  uint32_t s_begin;  // first sample index
+  uint32_t pad;
+  float* out;        // W*H*3 sums
+};
 struct FusedParams {
   uint32_t K, s_begin, s_stride, Ku;
   // Tile list.  The frame is cut into horizontal bands, each tiled with squares of its own side (8, 4 or 2 pixels):
@@ -290,6 +296,11 @@ struct FusedParams {
   // the classes the previous frame of the same scene and camera recorded (deepest first).
   const uint32_t* order;
   unsigned char* depth_out;
+  // Batches (rt_render_batch_device): the tile list is n_frames copies of the frame's list, list position T = frame *
+  // tiles_per_frame + tile; `frames` holds what differs between the frames (key, first sample index, output).  n_tiles is
+  // the whole list's length.  Paths of frame k + 1 are handed out while the deep paths of frame k drain.
+  const BatchFrame* frames;  // never NULL: a single frame is a table of one (FrameScratch::frame1), so the kernel has one path
+  uint32_t n_frames, tiles_per_frame;
   // Fixed-point format of the tile sums (to_fix / flush_finished): a sample channel is clamped to 2^20 and scaled by
   // 2^fix_bits, fix_bits = min(40, 43 - ceil(log2 K)), so that the K samples of a pixel cannot overflow the u64 slot
   // whatever they are (K <= 8: 2^-40 resolution; C2's 100: 2^-36; 10 000: 2^-29; the output is f32).
@@ -336,6 +347,13 @@ __device__ __forceinline__ void tile_geom(const FusedParams& fp, uint32_t t, uin
   x0 = tx << shift;
   y0 = fp.lvl_y0[lv] + (ty << shift);
 }
+// list position -> (frame, tile inside the frame); one frame: the position is the tile
+__device__ __forceinline__ void tile_split(const FusedParams& fp, uint32_t T, uint32_t& frame, uint32_t& tile) {
+  // (T is wave-uniform; the readfirstlane tells the compiler so — the values end up in scalar registers and addresses)
+  T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+  frame = 0; tile = T;
+  if (fp.n_frames > 1u) { frame = T / fp.tiles_per_frame; tile = T - frame * fp.tiles_per_frame; }
+}
 // sample indices per chunk for a tile of side 1 << shift: a chunk is about Ku x 64 paths whatever the tile's size
 __device__ __forceinline__ uint32_t chunk_samples(const FusedParams& fp, uint32_t shift) { return fp.Ku << (6u - 2u * shift); }
 
@@ -369,8 +387,13 @@ __device__ __forceinline__ unsigned long long to_fix(float v, float scale, unsig
   return (unsigned long long)(v * scale);
 }
 
-__global__ void k_store_camera(Camera cam, Camera* __restrict__ dst) {
-  if (threadIdx.x == 0) *dst = cam;
+// camera block and (single frames) the one-entry frame table travel as kernel arguments into their device slots:
+// stream-ordered, and no host buffer has to outlive an asynchronous copy
+__global__ void k_store_camera(Camera cam, Camera* __restrict__ dst, BatchFrame frame, BatchFrame* __restrict__ frame_dst) {
+  if (threadIdx.x == 0) {
+    *dst = cam;
+    if (frame_dst) *frame_dst = frame;
+  }
 }
 
 // Tile-order feedback: list position -> tile, deepest depth class first, raster order inside a class (a stable counting
@@ -497,7 +520,9 @@ __device__ __forceinline__ size_t lds_scene_setup(const Scene& sc, uint32_t nois
   return off;
 }
 
-template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS, bool RESUME>
+// BATCH = false: the single-frame form of every production instance — no frame index, key and first sample index straight
+// from the kernel arguments: compiled in, the batch bookkeeping measured 1.4-2.2 % on a C2 frame and 2 % on C5.
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS, bool RESUME, bool BATCH = true>
 __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __restrict__ camp, const FusedParams& fp, unsigned long long* __restrict__ tile_counter,
                                            float* __restrict__ out_sum, unsigned long long* __restrict__ ray_total,
                                            float* __restrict__ dbg) {
@@ -539,6 +564,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   // tile the workgroup opens.  Paths in flight keep accumulating into their own tile's slot, so lanes never idle through
   // a drain — only through the last one of the workgroup.
   uint32_t x0 = 0, y0 = 0, c_shift = 3, k_lo = 0, total = 0, next = 0, c_slot = 0;  // wave-uniform: current chunk and its pool cursor
+  uint32_t c_frame = 0;                      // wave-uniform: frame (of a batch) the current chunk belongs to
   bool exhausted = false;                    // wave-uniform: the frame has no more chunks
   bool opening = false;                      // wave-uniform: this wave has to open the workgroup's next tile
   bool active = false;
@@ -593,14 +619,16 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       fm &= fm - 1;
       const uint32_t s = (uint32_t)__builtin_amdgcn_readlane(flush_slot, l);
       const uint32_t tile_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched->tile[s]);
-      const uint32_t tile = tile_word & RT_TILE_MASK;
+      uint32_t frame = 0, tile = tile_word & RT_TILE_MASK;
+      if (BATCH) tile_split(fp, tile_word & RT_TILE_MASK, frame, tile);
       if (fp.depth_out && lane == 0) fp.depth_out[tile] = (unsigned char)__popc(tile_word >> 26);
       uint32_t tx0, ty0, tsh;
       tile_geom(fp, tile, tx0, ty0, tsh);
+      float* const frame_out = BATCH ? fp.frames[(uint32_t)__builtin_amdgcn_readfirstlane((int)frame)].out : out_sum;  // (uniform address: a scalar load)
       const uint32_t px = tx0 + (lane & ((1u << tsh) - 1u)), py = ty0 + (lane >> tsh);
       unsigned long long* a = l_acc + s * 192u + lane * 3u;
       if (lane < (1u << (2u * tsh)) && px < cam.width && py < cam.height) {
-        float* q = out_sum + ((size_t)py * cam.width + px) * 3;
+        float* q = frame_out + ((size_t)py * cam.width + px) * 3;
         q[0] = (float)((double)a[0] * fp.fix_inv);  // 2^-fix_bits
         q[1] = (float)((double)a[1] * fp.fix_inv);
         q[2] = (float)((double)a[2] * fp.fix_inv);
@@ -632,14 +660,20 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           const uint32_t t_back = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tc64 >> 32));
           const bool none_left = (unsigned long long)t_front + t_back >= fp.n_tiles;
           uint32_t t = fp.from_back ? fp.n_tiles - 1u - t_back : t_front;
-          if (fp.order && !none_left) t = fp.order[t];  // (uniform address: a scalar load)
+          uint32_t t_in = t;  // tile inside its frame
+          if (!none_left) {
+            if (BATCH) tile_split(fp, t, c_frame, t_in);
+            if (fp.order) t_in = fp.order[t_in];  // (uniform address: a scalar load)
+            if (BATCH) t = c_frame * fp.tiles_per_frame + t_in;
+            else t = t_in;
+          }
           opening = false;
           if (none_left) {
             exhausted = true;
             if (STATS && st_texh == 0.f) { st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f); st_abs_exh = wall_clock64(); }
             if (lane == 0) cursor_store(sp, RT_CUR_EXHAUSTED, fp.K);
           } else {
-            tile_geom(fp, t, x0, y0, c_shift);
+            tile_geom(fp, t_in, x0, y0, c_shift);
             const uint32_t side = 1u << c_shift;
             const uint32_t n_valid = min(side, cam.width - x0) * min(side, cam.height - y0);
             const uint32_t ks = chunk_samples(fp, c_shift);
@@ -667,8 +701,9 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           if ((uint32_t)c < fp.K) {
             // the chunk is as long as what this wave adds (sized for the tile it saw; another tile may have been opened
             // in between: then the chunk is merely longer or shorter than that tile's usual ones)
-            uint32_t gx, gy, gs;
-            tile_geom(fp, chi >> 6, gx, gy, gs);
+            uint32_t gx, gy, gs, gf = 0, gt = chi >> 6;
+            if (BATCH) tile_split(fp, chi >> 6, gf, gt);
+            tile_geom(fp, gt, gx, gy, gs);
             inc = chunk_samples(fp, gs);
             c = __hip_atomic_fetch_add(&sp->cursor, (unsigned long long)inc, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
           } else if (chi != RT_CUR_EXHAUSTED && chi != RT_CUR_OPENING) {
@@ -685,7 +720,9 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
         inc = (uint32_t)__builtin_amdgcn_readfirstlane((int)inc);
         if (k < fp.K) {
           c_slot = hi & 63u;
-          tile_geom(fp, hi >> 6, x0, y0, c_shift);
+          uint32_t t_in = hi >> 6;
+          if (BATCH) tile_split(fp, hi >> 6, c_frame, t_in);
+          tile_geom(fp, t_in, x0, y0, c_shift);
           k_lo = k;
           total = min(inc, fp.K - k) << (2u * c_shift);
         } else if (hi == RT_CUR_EXHAUSTED) {
@@ -708,10 +745,16 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
         const uint32_t px = x0 + (pit & ((1u << c_shift) - 1u)), py = y0 + (pit >> c_shift);
         if (px < cam.width && py < cam.height) {
           if (STATS) { st_regen += 1.f; st_wregen += wave_share(); }
-          uint32_t s = fp.s_begin + (k_lo + ks) * fp.s_stride;
+          // key and first sample index of the chunk's frame (a batch: from the frame table, scalar loads made here)
+          uint32_t f_k0 = fp.k0, f_k1 = fp.k1, f_s0 = fp.s_begin;
+          if (BATCH) {
+            const BatchFrame* bf = fp.frames + (uint32_t)__builtin_amdgcn_readfirstlane((int)c_frame);
+            f_k0 = bf->k0; f_k1 = bf->k1; f_s0 = bf->s_begin;
+          }
+          uint32_t s = f_s0 + (k_lo + ks) * fp.s_stride;
           const Camera* cp = camp;
           asm volatile("" : "+s"(cp));  // keep the camera loads here (not hoisted into long-lived SGPRs)
-          generate_ray(*cp, py, px, s, fp.k0, fp.k1, o, d, time, rng);
+          generate_ray(*cp, py, px, s, f_k0, f_k1, o, d, time, rng);
           thr = {1.f, 1.f, 1.f};
           depth = 0;
           lpix = c_slot * 64u + pit;
@@ -834,12 +877,12 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   }
 }
 
-template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
+template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false, bool BATCH = true>
 __global__ __launch_bounds__(BLOCK, fused_waves_per_simd(F, KIND, BLOCK)) void k_fused(Scene sc, const Camera* __restrict__ camp, FusedParams fp,
                                                                                        unsigned long long* __restrict__ tile_counter, float* __restrict__ out_sum,
                                                                                        unsigned long long* __restrict__ ray_total,
                                                                                        float* __restrict__ dbg = nullptr) {
-  fused_body<F, KIND, BLOCK, StackT, STATS, RESUME>(sc, camp, fp, tile_counter, out_sum, ray_total, dbg);
+  fused_body<F, KIND, BLOCK, StackT, STATS, RESUME, BATCH>(sc, camp, fp, tile_counter, out_sum, ray_total, dbg);
 }
 // The lean spheres-in-LDS instance (C1 / C2) with its own register ceiling: 4 x 104 VGPRs + the partner's 96 = 512, the
 // SIMD's register file (the attribute takes no template-dependent value, hence a kernel of its own).
@@ -847,18 +890,20 @@ __global__ __launch_bounds__(BLOCK, fused_waves_per_simd(F, KIND, BLOCK)) void k
 #ifndef RT_LEAN_VGPR_ATTR
 #define RT_LEAN_VGPR_ATTR 52
 #endif
-template <bool STATS, bool RESUME>
+template <bool STATS, bool RESUME, bool BATCH>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(RT_LEAN_VGPR_ATTR))) void k_fused_lean(Scene sc, const Camera* __restrict__ camp, FusedParams fp,
                                                                                             unsigned long long* __restrict__ tile_counter, float* __restrict__ out_sum,
                                                                                             unsigned long long* __restrict__ ray_total,
                                                                                             float* __restrict__ dbg = nullptr) {
-  fused_body<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, STATS, RESUME>(sc, camp, fp, tile_counter, out_sum, ray_total, dbg);
+  fused_body<RT_F_TEX_CHECKER, KIND_SPHERES_LDS, 1024, int16_t, STATS, RESUME, BATCH>(sc, camp, fp, tile_counter, out_sum, ray_total, dbg);
 }
 typedef void (*FusedKernel)(Scene, const Camera*, FusedParams, unsigned long long*, float*, unsigned long long*, float*);
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS, bool RESUME>
-static FusedKernel fused_kernel() {
-  if constexpr (F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && sizeof(StackT) == 2) return k_fused_lean<STATS, RESUME>;
-  else return k_fused<F, KIND, BLOCK, StackT, STATS, RESUME>;
+static FusedKernel fused_kernel(bool batch) {
+  if constexpr (F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && sizeof(StackT) == 2)
+    return batch ? k_fused_lean<STATS, RESUME, true> : k_fused_lean<STATS, RESUME, false>;
+  else if constexpr (STATS) return k_fused<F, KIND, BLOCK, StackT, STATS, RESUME, true>;  // (instrumented builds: the one form)
+  else return batch ? k_fused<F, KIND, BLOCK, StackT, STATS, RESUME, true> : k_fused<F, KIND, BLOCK, StackT, STATS, RESUME, false>;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ sum, uint32_t n_values, double inv_spp,
@@ -1070,6 +1115,7 @@ struct WorkBuffers {
 struct FrameScratch {
   unsigned long long* unit_counter = nullptr;  // [0] two-ended tile counter of the persistent kernel, [1] its watchdog flag
   Camera* cam = nullptr;                    // camera block of the render in flight (read with scalar loads)
+  BatchFrame* frame1 = nullptr;             // frame table of a single-frame render (key, first sample index, output)
   unsigned long long* ray_total = nullptr;  // 4 words: [0] rays traced, [1] NaN radiance channels, [2] clamped ones (stats)
 };
 
@@ -1141,6 +1187,10 @@ struct rt_ctx {
   // Device staging of the entry points that take HOST pointers (rt_render: the frame; rt_resolve: sums, f64 and u8
   // outputs; rt_intersect: rays and hits): grow-only, kept until rt_shutdown, so that a caller that renders pass after
   // pass (Camera::render_progressive) does not pay a hipMalloc + hipFree pair per call.
+  BatchFrame* d_batch = nullptr;  // frame table of rt_render_batch_device (grow-only)
+  size_t batch_cap = 0;
+  const BatchFrame* cur_frames = nullptr;  // batch being issued (render_fused), or NULL
+  uint32_t cur_n_frames = 1;
   void* stage[3] = {nullptr, nullptr, nullptr};
   size_t stage_cap[3] = {0, 0, 0};
 };
@@ -1251,6 +1301,7 @@ int rt_init(int device_id, rt_ctx** out) {
   if ((e = rti::dev_malloc(&ctx->own.ray_total, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = rti::dev_malloc(&ctx->own.unit_counter, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = rti::dev_malloc(&ctx->own.cam, sizeof(Camera))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = rti::dev_malloc(&ctx->own.frame1, sizeof(BatchFrame))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->own.ray_total, 0, 4 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   ctx->last_ray_total = ctx->own.ray_total;
   {
@@ -1261,6 +1312,7 @@ int rt_init(int device_id, rt_ctx** out) {
     unsigned char* b = static_cast<unsigned char*>(base);
     unsigned char* ctl = b;
     ctx->fixed.cam = reinterpret_cast<Camera*>(ctl);
+    ctx->fixed.frame1 = reinterpret_cast<BatchFrame*>(ctl + 640);
     ctx->fixed.ray_total = reinterpret_cast<unsigned long long*>(ctl + 512);
     ctx->fixed.unit_counter = reinterpret_cast<unsigned long long*>(ctl + 768);
   }
@@ -1307,6 +1359,7 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->own.ray_total) (void)rti::dev_free(ctx->own.ray_total);
   if (ctx->own.unit_counter) (void)rti::dev_free(ctx->own.unit_counter);
   if (ctx->own.cam) (void)rti::dev_free(ctx->own.cam);
+  if (ctx->own.frame1) (void)rti::dev_free(ctx->own.frame1);
   if (ctx->d_trav) (void)rti::dev_free(ctx->d_trav);
   if (ctx->d_bins) (void)rti::dev_free(ctx->d_bins);
   if (ctx->d_dbg) (void)rti::dev_free(ctx->d_dbg);
@@ -1314,6 +1367,7 @@ int rt_shutdown(rt_ctx* ctx) {
   if (ctx->d_noise_table) (void)rti::dev_free(ctx->d_noise_table);
   for (int i = 0; i < 3; i++)
     if (ctx->stage[i]) (void)rti::dev_free(ctx->stage[i]);
+  if (ctx->d_batch) (void)rti::dev_free(ctx->d_batch);
   if (ctx->ev_start) (void)rti::event_destroy(ctx->ev_start);
   if (ctx->ev_stop) (void)rti::event_destroy(ctx->ev_stop);
   if (ctx->ev_a) (void)rti::event_destroy(ctx->ev_a);
@@ -2102,7 +2156,8 @@ static bool partner_possible(const rt_ctx* ctx, const rt_scene* scene, size_t ld
   return lds_round(lds_main) + lds_round(fixed + 16 * 64) <= 160 * 1024;
 }
 static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams& fp_main, size_t lds_main, hipStream_t st) {
-  const FusedKernel kern = k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true>;
+  const FusedKernel kern = ctx->cur_frames ? k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true, true>
+                                           : k_fused<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 256, int16_t, false, true, false>;
   FusedParams fp = fp_main;  // same frame, same tile counter — taken from the other end
   fp.from_back = 1;
   fp.stack_depth = (uint32_t)scene->wide_stack + 2u;
@@ -2129,7 +2184,7 @@ static int launch_partner(rt_ctx* ctx, const rt_scene* scene, const FusedParams&
 template <uint32_t F, int KIND, int BLOCK, class StackT, bool STATS = false, bool RESUME = false>
 static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, const FusedParams& fp0, size_t smem,
                         hipStream_t st) {
-  const FusedKernel kern = fused_kernel<F, KIND, BLOCK, StackT, STATS, RESUME>();
+  const FusedKernel kern = fused_kernel<F, KIND, BLOCK, StackT, STATS, RESUME>(ctx->cur_frames != nullptr);
   // the LDS opt-in and the occupancy query cost tens of microseconds of host time: once per (instance, LDS size)
   const std::pair<const void*, size_t> key(reinterpret_cast<const void*>(kern), smem);
   auto cached = ctx->fused_occupancy.find(key);
@@ -2152,7 +2207,11 @@ static int launch_fused(rt_ctx* ctx, const rt_scene* scene, const Camera& dc, co
   if (ctx->dbg_main_cap > 0) blocks = std::min<uint32_t>(blocks, (uint32_t)ctx->dbg_main_cap);  // diagnostic
   // the camera travels as a kernel argument (captured at launch) into its device slot: stream-ordered, and no host
   // buffer has to outlive an asynchronous copy
-  hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->fs->cam);
+  {
+    BatchFrame one;
+    one.k0 = fp.k0; one.k1 = fp.k1; one.s_begin = fp.s_begin; one.pad = 0; one.out = ctx->cur_out;
+    hipLaunchKernelGGL(k_store_camera, dim3(1), dim3(64), 0, st, dc, ctx->fs->cam, one, ctx->cur_frames ? (BatchFrame*)nullptr : ctx->fs->frame1);
+  }
   constexpr bool kHasPartner = F == RT_F_TEX_CHECKER && KIND == KIND_SPHERES_LDS && BLOCK == 1024 && RESUME && !STATS;
   const bool partner = kHasPartner && per_cu == 1 && ctx->cur_partner;  // decided by render_fused (it shapes the tile list)
   if (partner) {
@@ -2197,6 +2256,9 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   memset(&fp, 0, sizeof(fp));
   fp.K = K; fp.s_begin = sample_begin; fp.s_stride = sample_stride;
   fp.k0 = (uint32_t)seed; fp.k1 = (uint32_t)(seed >> 32);
+  const uint32_t n_frames = ctx->cur_frames ? ctx->cur_n_frames : 1u;  // a batch: the frame table replaces seed / sample_begin / output
+  fp.frames = ctx->cur_frames ? ctx->cur_frames : ctx->fs->frame1;
+  fp.n_frames = n_frames;
   fp.poll_limit = ctx->dbg_watchdog_polls > 0 ? (uint32_t)ctx->dbg_watchdog_polls : (1u << 24);
   {
     int lg = 0;  // ceil(log2 K)
@@ -2228,7 +2290,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   // second launch and its join to pay (option fused_partner_min, Mi samples)
   ctx->cur_partner = ctx->fused_partner && lean && !ctx->fused_stats && scene->spheres_only && ctx->fused_lds && small_ids &&
                      lds_1024 <= 160 * 1024 && use_resume(ctx, scene) &&
-                     (uint64_t)cam->width * cam->height * K >= ((uint64_t)ctx->fused_partner_min << 20) &&
+                     (uint64_t)cam->width * cam->height * K * n_frames >= ((uint64_t)ctx->fused_partner_min << 20) &&
                      (uint64_t)cam->width * cam->height >= 64ull * 4 * (uint64_t)ctx->n_cu && partner_possible(ctx, scene, lds_1024);
   // tile slots: one per wave beside partner workgroups (they get the rest of the CU's LDS), two per wave otherwise
   fp.n_slots = 16;
@@ -2266,9 +2328,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
       y = y_end;
     }
     fp.lvl_begin[RT_TILE_LEVELS] = t;
-    fp.n_tiles = t;
-    // (a workgroup's LDS cursor carries tile << 6 | slot in 32 bits)
-    if (t >= (1u << 26)) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: frame too large (more than 2^26 tiles)");
+    fp.tiles_per_frame = t;
+    // (a workgroup's LDS cursor carries list position << 6 | slot in 32 bits)
+    if ((uint64_t)t * n_frames >= (1ull << 26)) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: more than 2^26 tiles (frame too large, or too many frames in the batch)");
+    fp.n_tiles = t * n_frames;
     fp.from_back = 0;
   }
   // Tile-order feedback: when the last fused frame of this context showed the same scene through the same camera with
@@ -2282,14 +2345,14 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   const bool in_lds = ctx->fused_lds && small_ids &&
                       (scene->spheres_only ? lds_1024 <= 160 * 1024 : lds_generic_1024 <= 160 * 1024);
   if (ctx->fused_feedback && in_lds && ctx->fs == &ctx->own) {
-    if (fp.n_tiles > ctx->tile_cap) {
+    if (fp.tiles_per_frame > ctx->tile_cap) {
       HIP_TRY(ctx, hipStreamSynchronize(st));
       if (ctx->d_tile_class) (void)rti::dev_free(ctx->d_tile_class);
       if (ctx->d_tile_order) (void)rti::dev_free(ctx->d_tile_order);
       ctx->d_tile_class = nullptr; ctx->d_tile_order = nullptr; ctx->tile_cap = 0; ctx->fb_valid = false;
-      HIP_TRY(ctx, rti::dev_malloc(&ctx->d_tile_class, fp.n_tiles));
-      HIP_TRY(ctx, rti::dev_malloc(&ctx->d_tile_order, (size_t)fp.n_tiles * sizeof(uint32_t)));
-      ctx->tile_cap = fp.n_tiles;
+      HIP_TRY(ctx, rti::dev_malloc(&ctx->d_tile_class, fp.tiles_per_frame));
+      HIP_TRY(ctx, rti::dev_malloc(&ctx->d_tile_order, (size_t)fp.tiles_per_frame * sizeof(uint32_t)));
+      ctx->tile_cap = fp.tiles_per_frame;
     }
     uint64_t key = 0xCBF29CE484222325ull;
     auto mix = [&key](const void* p, size_t n) {
@@ -2298,23 +2361,23 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     };
     mix(&scene->serial, sizeof(scene->serial));
     mix(cam, sizeof(*cam));
-    mix(&fp.n_tiles, sizeof(fp.n_tiles));
+    mix(&fp.tiles_per_frame, sizeof(fp.tiles_per_frame));
     mix(fp.lvl_begin, sizeof(fp.lvl_begin)); mix(fp.lvl_y0, sizeof(fp.lvl_y0)); mix(fp.lvl_shift, sizeof(fp.lvl_shift));
     // The classes are written by the previous frame's kernels and read twice by k_order_tiles: that is ordered only
     // through the stream, so a frame issued on another stream than its predecessor starts from image order.
     if (ctx->fb_stream != st) ctx->fb_valid = false;
     ctx->fb_stream = st;
     if (ctx->fb_valid && key == ctx->fb_key) {
-      hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, st, ctx->d_tile_class, ctx->d_tile_order, fp.n_tiles);
+      hipLaunchKernelGGL(k_order_tiles, dim3(1), dim3(1024), 0, st, ctx->d_tile_class, ctx->d_tile_order, fp.tiles_per_frame);
       fp.order = ctx->d_tile_order;
     }
     if (fp.order && getenv("RT_VERBOSE")) {  // diagnostic: what the previous frame recorded
-      std::vector<unsigned char> h(fp.n_tiles);
+      std::vector<unsigned char> h(fp.tiles_per_frame);
       HIP_TRY(ctx, hipStreamSynchronize(st));
-      HIP_TRY(ctx, hipMemcpy(h.data(), ctx->d_tile_class, fp.n_tiles, hipMemcpyDeviceToHost));
+      HIP_TRY(ctx, hipMemcpy(h.data(), ctx->d_tile_class, fp.tiles_per_frame, hipMemcpyDeviceToHost));
       size_t c[4] = {0, 0, 0, 0};
       for (unsigned char v : h) c[std::min<int>(3, v)]++;
-      fprintf(stderr, "[rt] tile order from depth classes: %zu shallow, %zu (>=6), %zu (>=12), %zu (>=24) of %u tiles\n", c[0], c[1], c[2], c[3], fp.n_tiles);
+      fprintf(stderr, "[rt] tile order from depth classes: %zu shallow, %zu (>=6), %zu (>=12), %zu (>=24) of %u tiles\n", c[0], c[1], c[2], c[3], fp.tiles_per_frame);
     }
     fp.depth_out = ctx->d_tile_class;
     ctx->fb_key = key;
@@ -2453,6 +2516,74 @@ int rt_render_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, u
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,
                              uint32_t sample_end, uint32_t sample_stride, float* d_out_sum, void* hip_stream) {
   return render_device_impl(ctx, scene, cam, seed, sample_begin, sample_end, sample_stride, d_out_sum, hip_stream, true);
+}
+
+// Several frames of one scene and camera in ONE persistent launch: the tile list is the frames' lists back to back, so
+// the workgroups hand out frame k + 1 while the deepest paths of frame k still bounce — the ~0.4 ms drain that every
+// separately launched frame pays is paid once per batch.  Every frame is bit-identical to what
+// rt_render_device gives for the same (seed, sample_begin, sample_end, sample_stride).
+int rt_render_batch_device(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint32_t n_frames, const uint64_t* seeds,
+                           const uint32_t* sample_begins, uint32_t sample_end, uint32_t sample_stride, float* const* d_out_sums,
+                           void* hip_stream) {
+  if (!ctx) return RT_E_INVALID_ARG;
+  if (!scene || !cam || !seeds || !sample_begins || !d_out_sums || n_frames == 0)
+    return fail(ctx, RT_E_INVALID_ARG, "rt_render_batch_device: NULL argument or empty batch");
+  if (n_frames > 65536) return fail(ctx, RT_E_UNSUPPORTED, "rt_render_batch_device: more than 65536 frames in one batch");
+  if (sample_stride == 0) return fail(ctx, RT_E_INVALID_ARG, "rt_render: sample_stride must be >= 1");
+  if (ctx->mode != 1) return fail(ctx, RT_E_UNSUPPORTED, "rt_render_batch_device: only the fused mode (option mode = 1) renders batches");
+  Camera dc;
+  int rc = to_device_camera(ctx, cam, dc);
+  if (rc) return rc;
+  const uint64_t spp_total = cam->sampler_kind == RT_SAMPLER_UNIFORM ? (uint64_t)cam->sampler_n * cam->sampler_n : cam->sampler_n;
+  if (sample_end > spp_total) return fail(ctx, RT_E_INVALID_ARG, "rt_render: sample_end exceeds the sampler's sample count");
+  // every frame renders the same NUMBER of sample indices (the kernel hands out tiles of K samples per pixel)
+  uint64_t K64 = 0;
+  std::vector<BatchFrame> table(n_frames);
+  for (uint32_t i = 0; i < n_frames; i++) {
+    if (!d_out_sums[i]) return fail(ctx, RT_E_INVALID_ARG, "rt_render_batch_device: NULL output pointer");
+    const uint64_t k = sample_begins[i] < sample_end ? ((uint64_t)(sample_end - sample_begins[i]) + sample_stride - 1) / sample_stride : 0;
+    if (i == 0) K64 = k;
+    if (k != K64 || k == 0)
+      return fail(ctx, RT_E_INVALID_ARG, "rt_render_batch_device: every frame of a batch must select the same, non-zero number of sample "
+                                         "indices (split the batch)");
+    table[i].k0 = (uint32_t)seeds[i]; table[i].k1 = (uint32_t)(seeds[i] >> 32);
+    table[i].s_begin = sample_begins[i]; table[i].pad = 0; table[i].out = d_out_sums[i];
+  }
+  if (K64 > 65535ull * 64ull) return fail(ctx, RT_E_UNSUPPORTED, "rt_render: too many samples per pixel in one call");
+  const uint32_t K = (uint32_t)K64;
+  const uint32_t n_pix = cam->width * cam->height;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+  ctx->fs = &ctx->own;
+  ctx->stats = rt_stats();
+  ctx->ms_bin = 0.f;
+  if (ctx->batch_cap < n_frames) {
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->d_batch) (void)rti::dev_free(ctx->d_batch);
+    ctx->d_batch = nullptr; ctx->batch_cap = 0;
+    HIP_TRY(ctx, rti::dev_malloc(&ctx->d_batch, (size_t)n_frames * sizeof(BatchFrame)));
+    ctx->batch_cap = n_frames;
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_start, st));
+  // (pageable source: the runtime stages the table before the call returns, so `table` may go out of scope)
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_batch, table.data(), (size_t)n_frames * sizeof(BatchFrame), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->fs->ray_total, 0, 4 * sizeof(unsigned long long), st));
+  ctx->last_ray_total = ctx->fs->ray_total;
+  ctx->last_watchdog = nullptr;
+  if (cam->max_depth > 0) {
+    ctx->stats.paths = (uint64_t)n_pix * K * n_frames;
+    ctx->cur_frames = ctx->d_batch;
+    ctx->cur_n_frames = n_frames;
+    rc = render_fused(ctx, scene, cam, dc, seeds[0], sample_begins[0], sample_stride, K, d_out_sums[0], st);
+    ctx->cur_frames = nullptr;
+    ctx->cur_n_frames = 1;
+    if (rc) return rc;
+  } else {
+    for (uint32_t i = 0; i < n_frames; i++) HIP_TRY(ctx, hipMemsetAsync(d_out_sums[i], 0, (size_t)n_pix * 3 * sizeof(float), st));
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, st));
+  ctx->timing_pending = true;
+  return RT_OK;
 }
 
 int rt_render(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam, uint64_t seed, uint32_t sample_begin,

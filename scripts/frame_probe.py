@@ -8,12 +8,14 @@ import raytracer_amd as ra
 
 ctx = ra.Context(0)
 opts = {}
-stride, frames = 1, 20
+stride, frames, batch = 1, 20, 0
 for a in sys.argv[1:]:
     if a.startswith("--stride="):
         stride = int(a.split("=")[1])
     elif a.startswith("--frames="):
         frames = int(a.split("=")[1])
+    elif a.startswith("--batch="):
+        batch = int(a.split("=")[1])  # frames per rt_render_batch_device launch (0: one rt_render_device launch per frame)
     elif a.startswith("--workload="):
         pass
     elif "=" in a:
@@ -37,11 +39,23 @@ st = torch.cuda.current_stream().cuda_stream
 for _ in range(3):
     dev.render_device(cam, d.data_ptr(), seed=1, sample_begin=0, sample_stride=stride, stream=st)
 torch.cuda.synchronize()
+end = (spp // stride) * stride  # (every frame of a batch must select the same number of sample indices)
+if batch:
+    outs = [torch.zeros_like(d) for _ in range(batch)]
+    ptrs = [o.data_ptr() for o in outs]
+    ra.render_batch_device(dev, cam, ptrs, list(range(batch)), [i % stride for i in range(batch)], sample_end=end, sample_stride=stride, stream=st)
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
-for i in range(frames):
-    dev.render_device(cam, d.data_ptr(), seed=1 + i, sample_begin=i % stride, sample_stride=stride, stream=st)
+if batch:
+    for b0 in range(0, frames, batch):
+        ra.render_batch_device(dev, cam, ptrs, [1 + b0 + i for i in range(batch)], [(b0 + i) % stride for i in range(batch)],
+                               sample_end=end, sample_stride=stride, stream=st)
+    frames = (frames + batch - 1) // batch * batch
+else:
+    for i in range(frames):
+        dev.render_device(cam, d.data_ptr(), seed=1 + i, sample_begin=i % stride, sample_end=end, sample_stride=stride, stream=st)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / frames * 1e3
 s = ctx.stats()
-print(json.dumps({"workload": wl, "opts": opts, "stride": stride, "ms": round(ms, 3), "kernel_ms": round(s["ms_total"], 3),
+print(json.dumps({"workload": wl, "opts": opts, "stride": stride, "batch": batch, "ms": round(ms, 3), "kernel_ms": round(s["ms_total"], 3),
                   "front": s["dbg"][14], "back": s["dbg"][15]}))
