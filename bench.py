@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the block of the other BASELINE configs on the N = 1 line")
     ap.add_argument("--no-c5-full", action="store_true", help="skip BASELINE config 5 at its full 10 000 spp (about half a minute)")
+    ap.add_argument("--lean-run", action="store_true",
+                    help="profiling runs (scripts/gpu_profile.sh): only launches of the production kernel — no instrumented frame, "
+                         "no feedback-off leg, no batched leg")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="rt_set_option override (profiling runs: fused_partner=0, rocprofv3 serialises kernels)")
     ap.add_argument("--rehearse", action="store_true",
@@ -366,9 +369,9 @@ def main():
              "first_frame_note": "wall time of the first rt_render_device call of this process on this rank (cold: code-object "
                                  "load, LDS opt-in, occupancy query, tile order unprimed), scene already uploaded"}
     own = None
-    if rank == 0:
+    if rank == 0 and not args.lean_run:
         own = measure_own_tree(ctx, rig, stream, d_sum.data_ptr())
-    if world == 1 and args.workload in ("c1", "c2", "c4"):
+    if world == 1 and args.workload in ("c1", "c2", "c4") and not args.lean_run:
         # steady state without the tile order learned from the previous frame of the same view
         ctx.set_option("fused_feedback", 0)
         el_off = timed(step_strong, max(3, min(args.steps, 10)), 1)
@@ -378,7 +381,7 @@ def main():
     # persistent launch, then B reduces and resolves: the per-frame drain of the deepest paths is paid once per batch
     # instead of once per frame, which is what limits strong scaling of a 9 ms frame.  Secondary field;
     # `value` stays the one-launch-per-frame figure (the reference renders one frame per call).
-    if args.workload in ("c1", "c2"):
+    if args.workload in ("c1", "c2") and not args.lean_run:
         B = 8
         b_, e_, s_ = mg.sample_slice(rank, world, rig.spp)
         # every frame of a batch must select the same number of sample indices: this rank's slice as it is

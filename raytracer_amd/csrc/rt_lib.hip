@@ -337,25 +337,49 @@ constexpr bool kind_caches_top(int k) { return k == KIND_GENERIC_WIDE_HALF || k 
 constexpr bool kind_in_lds(int k) { return k == KIND_SPHERES_LDS || k == KIND_GENERIC_LDS; }
 
 // tile index -> top-left pixel and log2 of the tile's side (all wave-uniform)
-__device__ __forceinline__ void tile_geom(const FusedParams& fp, uint32_t t, uint32_t& x0, uint32_t& y0, uint32_t& shift) {
+// The kernel's FusedParams as the scheduling code reads it: through a pointer into the kernel-argument segment (constant
+// address space, scalar loads) made opaque where it is used, NOT through the by-value argument — fields read that way are
+// loaded where the (rare) tile / chunk bookkeeping runs instead of being held in scalar registers across the whole render
+// loop, where they were spilled to VGPR lanes (v_writelane / v_readlane) and those VGPRs in turn to scratch.
+typedef const __attribute__((address_space(4))) FusedParams* ColdParams;
+// argument list of k_fused / k_fused_lean, to locate FusedParams in the kernel-argument segment
+struct FusedKernelArgs {
+  Scene sc;
+  const Camera* camp;
+  FusedParams fp;
+  unsigned long long* tile_counter;
+  float* out_sum;
+  unsigned long long* ray_total;
+  float* dbg;
+};
+__device__ __forceinline__ ColdParams cold_params() {
+  const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  ColdParams p = (ColdParams)(ka + offsetof(FusedKernelArgs, fp));
+  asm volatile("" : "+s"(p));
+  return p;
+}
+template <class P>
+__device__ __forceinline__ void tile_geom(P fp, uint32_t t, uint32_t& x0, uint32_t& y0, uint32_t& shift) {
   uint32_t lv = 0;
 #pragma unroll
-  for (uint32_t i = 1; i < RT_TILE_LEVELS; i++) lv = t >= fp.lvl_begin[i] ? i : lv;
-  const uint32_t local = t - fp.lvl_begin[lv];
-  shift = fp.lvl_shift[lv];
-  const uint32_t ty = local / fp.lvl_tiles_x[lv], tx = local - ty * fp.lvl_tiles_x[lv];
+  for (uint32_t i = 1; i < RT_TILE_LEVELS; i++) lv = t >= fp->lvl_begin[i] ? i : lv;
+  const uint32_t local = t - fp->lvl_begin[lv];
+  shift = fp->lvl_shift[lv];
+  const uint32_t ty = local / fp->lvl_tiles_x[lv], tx = local - ty * fp->lvl_tiles_x[lv];
   x0 = tx << shift;
-  y0 = fp.lvl_y0[lv] + (ty << shift);
+  y0 = fp->lvl_y0[lv] + (ty << shift);
 }
 // list position -> (frame, tile inside the frame); one frame: the position is the tile
-__device__ __forceinline__ void tile_split(const FusedParams& fp, uint32_t T, uint32_t& frame, uint32_t& tile) {
+template <class P>
+__device__ __forceinline__ void tile_split(P fp, uint32_t T, uint32_t& frame, uint32_t& tile) {
   // (T is wave-uniform; the readfirstlane tells the compiler so — the values end up in scalar registers and addresses)
   T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
   frame = 0; tile = T;
-  if (fp.n_frames > 1u) { frame = T / fp.tiles_per_frame; tile = T - frame * fp.tiles_per_frame; }
+  if (fp->n_frames > 1u) { frame = T / fp->tiles_per_frame; tile = T - frame * fp->tiles_per_frame; }
 }
 // sample indices per chunk for a tile of side 1 << shift: a chunk is about Ku x 64 paths whatever the tile's size
-__device__ __forceinline__ uint32_t chunk_samples(const FusedParams& fp, uint32_t shift) { return fp.Ku << (6u - 2u * shift); }
+template <class P>
+__device__ __forceinline__ uint32_t chunk_samples(P fp, uint32_t shift) { return fp->Ku << (6u - 2u * shift); }
 
 // The scheduler block's LDS address, made opaque at the point of use: the cold scheduling code then forms its per-lane
 // addresses where it runs instead of holding them in VGPRs across the whole render loop (where they get spilled).
@@ -571,7 +595,11 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
   d3 o = {0, 0, 0}, d = {0, 0, 0};
   double time = 0;
   f3 thr = {1.f, 1.f, 1.f};
-  uint32_t depth = 0, lpix = 0;  // lpix: slot * 64 + pixel index inside the tile
+  // one register for two small values: low 12 bits = lpix (slot * 64 + pixel index inside the tile), the rest = depth
+  // (saturating at 2^20 - 1: a max_depth beyond that is never reached by a path anyway)
+  uint32_t dl = 0;
+#define RT_LPIX (dl & 4095u)
+#define RT_DEPTH (dl >> 12)
   PathRng rng = {0, 0};
   // RESUME: the lane's traversal progress (node, stack, best hit) survives shade / regenerate rounds of its
   // neighbours; the per-ray constants are recomputed each round (unconditionally, so that they are not live across
@@ -591,15 +619,16 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     if (!alive) {
       const unsigned long long r = to_fix(so.radiance.x, fp.fix_scale, ray_total), g = to_fix(so.radiance.y, fp.fix_scale, ray_total),
                                b = to_fix(so.radiance.z, fp.fix_scale, ray_total);
-      if (r) atomicAdd(&l_acc[lpix * 3 + 0], r);
-      if (g) atomicAdd(&l_acc[lpix * 3 + 1], g);
-      if (b) atomicAdd(&l_acc[lpix * 3 + 2], b);
+      if (r) atomicAdd(&l_acc[RT_LPIX * 3 + 0], r);
+      if (g) atomicAdd(&l_acc[RT_LPIX * 3 + 1], g);
+      if (b) atomicAdd(&l_acc[RT_LPIX * 3 + 2], b);
     } else {
-      depth++;
-      if (depth >= cam.max_depth) alive = false;  // mod.rs:195-197: black
+      if (RT_DEPTH < 0xFFFFFu) dl += 4096u;
+      if (RT_DEPTH >= cam.max_depth) alive = false;  // mod.rs:195-197: black
     }
     if (!alive) {
       // deep paths mark their tile (tile-order feedback: such tiles go first in the next frame of this view)
+      const uint32_t depth = RT_DEPTH, lpix = RT_LPIX;
       if (depth >= 6u) __hip_atomic_fetch_or(&sched->tile[lpix >> 6], depth >= 24u ? (7u << 26) : depth >= 12u ? (3u << 26) : (1u << 26),
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       // one path fewer in flight for its tile.  acq_rel at workgroup scope: the adds above are in LDS before the count
@@ -620,18 +649,21 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       const uint32_t s = (uint32_t)__builtin_amdgcn_readlane(flush_slot, l);
       const uint32_t tile_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)sched->tile[s]);
       uint32_t frame = 0, tile = tile_word & RT_TILE_MASK;
-      if (BATCH) tile_split(fp, tile_word & RT_TILE_MASK, frame, tile);
-      if (fp.depth_out && lane == 0) fp.depth_out[tile] = (unsigned char)__popc(tile_word >> 26);
+      const ColdParams cfp = cold_params();
+      if (BATCH) tile_split(cfp, tile_word & RT_TILE_MASK, frame, tile);
+      unsigned char* const depth_out = cfp->depth_out;
+      if (depth_out && lane == 0) depth_out[tile] = (unsigned char)__popc(tile_word >> 26);
       uint32_t tx0, ty0, tsh;
-      tile_geom(fp, tile, tx0, ty0, tsh);
-      float* const frame_out = BATCH ? fp.frames[(uint32_t)__builtin_amdgcn_readfirstlane((int)frame)].out : out_sum;  // (uniform address: a scalar load)
+      tile_geom(cfp, tile, tx0, ty0, tsh);
+      float* const frame_out = BATCH ? cfp->frames[(uint32_t)__builtin_amdgcn_readfirstlane((int)frame)].out : out_sum;  // (uniform address: a scalar load)
+      const double fix_inv = cfp->fix_inv;
       const uint32_t px = tx0 + (lane & ((1u << tsh) - 1u)), py = ty0 + (lane >> tsh);
       unsigned long long* a = l_acc + s * 192u + lane * 3u;
       if (lane < (1u << (2u * tsh)) && px < cam.width && py < cam.height) {
         float* q = frame_out + ((size_t)py * cam.width + px) * 3;
-        q[0] = (float)((double)a[0] * fp.fix_inv);  // 2^-fix_bits
-        q[1] = (float)((double)a[1] * fp.fix_inv);
-        q[2] = (float)((double)a[2] * fp.fix_inv);
+        q[0] = (float)((double)a[0] * fix_inv);  // 2^-fix_bits
+        q[1] = (float)((double)a[1] * fix_inv);
+        q[2] = (float)((double)a[2] * fix_inv);
       }
       a[0] = 0; a[1] = 0; a[2] = 0;
       if (lane == 0) __hip_atomic_store(&sched->state[s], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -641,6 +673,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
     // ---- next chunk when the pool is empty
     if (next >= total && !exhausted) {
       LdsSched* const sp = sched_here(sched);
+      const ColdParams cfp = cold_params();  // tile / chunk bookkeeping reads the parameters where it runs
       total = 0; next = 0;
       if (opening) {
         // open the workgroup's next tile in a free slot (none free: every slot still waits for paths in flight — try
@@ -652,40 +685,40 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           // one 64-bit counter for both ends of the tile list (see FusedParams)
           unsigned long long tc64 = 0;
           if (lane == 0) {
-            uint32_t back = fp.from_back;
+            uint32_t back = cfp->from_back;
             asm volatile("" : "+s"(back));  // the increment is built here, not kept in VGPRs across the render loop
             tc64 = atomicAdd(tile_counter, (unsigned long long)(back ^ 1u) | ((unsigned long long)back << 32));
           }
           const uint32_t t_front = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tc64);
           const uint32_t t_back = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tc64 >> 32));
-          const bool none_left = (unsigned long long)t_front + t_back >= fp.n_tiles;
-          uint32_t t = fp.from_back ? fp.n_tiles - 1u - t_back : t_front;
+          const bool none_left = (unsigned long long)t_front + t_back >= cfp->n_tiles;
+          uint32_t t = cfp->from_back ? cfp->n_tiles - 1u - t_back : t_front;
           uint32_t t_in = t;  // tile inside its frame
           if (!none_left) {
-            if (BATCH) tile_split(fp, t, c_frame, t_in);
-            if (fp.order) t_in = fp.order[t_in];  // (uniform address: a scalar load)
-            if (BATCH) t = c_frame * fp.tiles_per_frame + t_in;
+            if (BATCH) tile_split(cfp, t, c_frame, t_in);
+            if (cfp->order) t_in = cfp->order[t_in];  // (uniform address: a scalar load)
+            if (BATCH) t = c_frame * cfp->tiles_per_frame + t_in;
             else t = t_in;
           }
           opening = false;
           if (none_left) {
             exhausted = true;
             if (STATS && st_texh == 0.f) { st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f); st_abs_exh = wall_clock64(); }
-            if (lane == 0) cursor_store(sp, RT_CUR_EXHAUSTED, fp.K);
+            if (lane == 0) cursor_store(sp, RT_CUR_EXHAUSTED, cfp->K);
           } else {
-            tile_geom(fp, t_in, x0, y0, c_shift);
+            tile_geom(cfp, t_in, x0, y0, c_shift);
             const uint32_t side = 1u << c_shift;
             const uint32_t n_valid = min(side, cam.width - x0) * min(side, cam.height - y0);
-            const uint32_t ks = chunk_samples(fp, c_shift);
+            const uint32_t ks = chunk_samples(cfp, c_shift);
             if (lane == 0) {
               sp->tile[s] = t;
-              sp->rem[s] = n_valid * fp.K;
+              sp->rem[s] = n_valid * cfp->K;
               sp->state[s] = 1u;
               // the opener keeps the tile's first chunk; release: the slot's words are in LDS before the cursor moves
               cursor_store(sp, (t << 6) | s, ks);
             }
             c_slot = s; k_lo = 0;
-            total = min(ks, fp.K) << (2u * c_shift);
+            total = min(ks, cfp->K) << (2u * c_shift);
           }
         }
       } else {
@@ -698,17 +731,17 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
         if (lane == 0) {
           c = __hip_atomic_load(&sp->cursor, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
           const uint32_t chi = (uint32_t)(c >> 32);
-          if ((uint32_t)c < fp.K) {
+          if ((uint32_t)c < cfp->K) {
             // the chunk is as long as what this wave adds (sized for the tile it saw; another tile may have been opened
             // in between: then the chunk is merely longer or shorter than that tile's usual ones)
             uint32_t gx, gy, gs, gf = 0, gt = chi >> 6;
-            if (BATCH) tile_split(fp, chi >> 6, gf, gt);
-            tile_geom(fp, gt, gx, gy, gs);
-            inc = chunk_samples(fp, gs);
+            if (BATCH) tile_split(cfp, chi >> 6, gf, gt);
+            tile_geom(cfp, gt, gx, gy, gs);
+            inc = chunk_samples(cfp, gs);
             c = __hip_atomic_fetch_add(&sp->cursor, (unsigned long long)inc, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
           } else if (chi != RT_CUR_EXHAUSTED && chi != RT_CUR_OPENING) {
             unsigned long long expect = c;
-            uint32_t want_hi = RT_CUR_OPENING, want_lo = fp.K;
+            uint32_t want_hi = RT_CUR_OPENING, want_lo = cfp->K;
             asm volatile("" : "+s"(want_hi), "+s"(want_lo));  // built here, not hoisted out of the render loop
             won = __hip_atomic_compare_exchange_strong(&sp->cursor, &expect, ((unsigned long long)want_hi << 32) | want_lo,
                                                        __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
@@ -718,13 +751,13 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c >> 32));
         won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
         inc = (uint32_t)__builtin_amdgcn_readfirstlane((int)inc);
-        if (k < fp.K) {
+        if (k < cfp->K) {
           c_slot = hi & 63u;
           uint32_t t_in = hi >> 6;
-          if (BATCH) tile_split(fp, hi >> 6, c_frame, t_in);
-          tile_geom(fp, t_in, x0, y0, c_shift);
+          if (BATCH) tile_split(cfp, hi >> 6, c_frame, t_in);
+          tile_geom(cfp, t_in, x0, y0, c_shift);
           k_lo = k;
-          total = min(inc, fp.K - k) << (2u * c_shift);
+          total = min(inc, cfp->K - k) << (2u * c_shift);
         } else if (hi == RT_CUR_EXHAUSTED) {
           exhausted = true;
           if (STATS && st_texh == 0.f) { st_texh = (float)(now_cycles() - st_tk) * (1.0f / 64.0f); st_abs_exh = wall_clock64(); }
@@ -756,8 +789,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
           asm volatile("" : "+s"(cp));  // keep the camera loads here (not hoisted into long-lived SGPRs)
           generate_ray(*cp, py, px, s, f_k0, f_k1, o, d, time, rng);
           thr = {1.f, 1.f, 1.f};
-          depth = 0;
-          lpix = c_slot * 64u + pit;
+          dl = c_slot * 64u + pit;  // depth 0
           active = true;
           fresh_lane = true;
         }
@@ -787,7 +819,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
             if (lane == 0) chi = (uint32_t)(__hip_atomic_load(&sp->cursor, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
             go = (uint32_t)__builtin_amdgcn_readfirstlane((int)chi) != RT_CUR_OPENING;
           }
-        } while (!go && ++polls < fp.poll_limit);
+        } while (!go && ++polls < cold_params()->poll_limit);
         if (STATS) { st_twait += (float)(now_cycles() - st_t0) * (1.0f / 64.0f); }
         if (!go) {
           if (lane == 0) atomicOr(reinterpret_cast<uint32_t*>(tile_counter + 1), 1u);

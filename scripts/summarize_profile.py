@@ -8,7 +8,7 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), f"profiles/{tag}_kernel_stats.csv")
-out = {"command": "rocprofv3 --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-workloads --no-strong-workloads "
+out = {"command": "rocprofv3 --pmc <counters> -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --lean-run --no-workloads --no-strong-workloads "
                   "--option fused_partner=0" + ("" if workload == "c2" else " --workload " + workload) + " (one pass per group)",
        "workload": workload,
        "kernel": None, "counters": {}}
