@@ -846,7 +846,10 @@ __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPr
 template <class Acc>
 __device__ __forceinline__ void count_leaf_type(const Acc& acc, int32_t pi, TravCounters* cnt) {
   const uint32_t ty = acc.type(pi);
-  cnt->t_sph += ty == 0u; cnt->t_mov += ty == 1u; cnt->t_quad += ty == 2u; cnt->t_med += ty == 3u || ty == 4u; cnt->t_box += ty == RT_PRIM_AABOX;
+  cnt->t_sph += ty == 0u; cnt->t_mov += ty == 1u;
+  if constexpr (!Acc::kSpheresOnly) {  // (sphere scenes: two live counters instead of five in a register-capped kernel)
+    cnt->t_quad += ty == 2u; cnt->t_med += ty == 3u || ty == 4u; cnt->t_box += ty == RT_PRIM_AABOX;
+  }
 }
 
 // Closest hit over t in (tmin, +inf) exclusive.  `stack` points at this lane's column of the LDS short
