@@ -284,6 +284,7 @@ struct GlobalAcc {
   static constexpr bool kSpheresOnly = false;
   static constexpr bool kPrimsInHbm = true;
   static constexpr bool kWide = false;
+  static constexpr bool kSlabLds = false;  // 112-byte slab nodes in LDS (node_loop_slab16)
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -309,6 +310,7 @@ struct SphereAcc {
   static constexpr bool kSpheresOnly = true;
   static constexpr bool kPrimsInHbm = true;
   static constexpr bool kWide = false;
+  static constexpr bool kSlabLds = false;  // 112-byte slab nodes in LDS (node_loop_slab16)
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -344,6 +346,7 @@ struct SlabLdsAcc {
   static constexpr bool kSpheresOnly = true;
   static constexpr bool kPrimsInHbm = false;
   static constexpr bool kWide = false;
+  static constexpr bool kSlabLds = true;  // 112-byte slab nodes in LDS (node_loop_slab16)
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -372,6 +375,7 @@ struct GenericLdsAcc {
   static constexpr bool kSpheresOnly = false;
   static constexpr bool kPrimsInHbm = false;
   static constexpr bool kWide = false;
+  static constexpr bool kSlabLds = true;  // 112-byte slab nodes in LDS (node_loop_slab16)
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -474,6 +478,21 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
+// sqrt of a non-negative f64 with the iteration the compiler's own expansion uses (v_rsq_f64 start, two Goldschmidt
+// steps, two residual corrections: correctly rounded in practice, the same bits as __builtin_sqrt for x >= 1e-300)
+// without its range scaling and class tests: 11 instructions instead of 19.  Arguments below 1e-300 (a discriminant
+// that is exactly 0: a tangent ray) give 1e-150 instead of 0.
+__device__ __forceinline__ double fast_sqrt_nonneg(double x) {
+  x = __builtin_fmax(x, 1e-300);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return g;
+}
 // src/hittable/geometry.rs:36-57 — sphere quadratic in f64, evaluated in the reference's operation order
 // with contraction off so that `t` is bit-identical to the CPU path for identical inputs.
 #pragma clang fp contract(off)
@@ -495,7 +514,7 @@ __device__ __forceinline__ bool sphere_hit(const PrimGeom& g, d3 o, d3 d, double
   double surface = (oc.x * oc.x + oc.y * oc.y + oc.z * oc.z) - r * r;
   double disc = alignment * alignment - a * surface;
   if (disc < 0.) return false;
-  double sq = __builtin_sqrt(disc);
+  double sq = fast_sqrt_nonneg(disc);
   double root = (-alignment - sq) * inv_a;
   if (!(tmin < root && root < tmax)) {
     root = (-alignment + sq) * inv_a;
@@ -591,7 +610,7 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
     double cc = dot(oc, oc) - P.f[6] * P.f[6];
     double disc = hb * hb - a * cc;
     if (disc < 0.) return false;
-    double sq = __builtin_sqrt(disc);
+    double sq = fast_sqrt_nonneg(disc);
     t1 = (-hb - sq) * inv_a;
     t2 = (-hb + sq) * inv_a;
   } else {
@@ -757,6 +776,88 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
     if (!hl && !hr) trav_pop(ts, stack, stride);
   }
 }
+// The inner-node loop of the LDS-resident slab-node traversals (SlabLdsAcc / GenericLdsAcc, 16-bit stacks) as ONE asm
+// statement: `while (at least `need` lanes are at an inner node) those lanes take a node_step`.  Same instructions on
+// the same operands as node_step() — results are bit-identical — but the loop-carried values (cur, sp, top) stay in the
+// registers they live in.  Compiled from the C++ form, every step carried six v_mov of loop-exit copies (cur, sp and top
+// each existed twice) and waited for the pop's refill load before the next node's fetches were issued: 33 VALU
+// instructions per step, 27 here, and the refill overlaps the next fetch.  The kernel's time IS its VALU instruction
+// count, and this loop is half of it.
+// Temporaries are v80..v93 by name (the plane quads' halves must be addressable as register pairs, which asm operands
+// are not): qx v[80:83], qy v[84:87], qz v[88:91], child links / node address v[92:93].
+// Hazards (no assembler help inside asm): every VALU read of a VALU-written SGPR pair is >= 2 instructions behind its
+// v_cmp (gfx940 rule); LDS returns in order, so lgkmcnt(3..0) after the four fetches also covers the push / refill of
+// the step before; exec is restored before the back edge and on exit.
+#ifndef RT_ASM_NODE_LOOP
+#define RT_ASM_NODE_LOOP 1
+#endif
+template <class Acc>
+__device__ __forceinline__ void node_loop_slab16(const Acc& acc, TravState& ts, int stride_bytes, uint32_t need) {
+  const uint32_t base = (uint32_t)lds_addr(acc.nodes);
+  unsigned long long m_walk, m_save, m_hr, m_lf, m_t;
+  uint32_t n_walk;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n"
+      "1:\n"
+      "v_cmp_lt_i32_e64 %[mw], -1, %[cur]\n"
+      "s_bcnt1_i32_b64 %[nw], %[mw]\n"
+      "s_cmp_lt_u32 %[nw], %[need]\n"
+      "s_cbranch_scc1 2f\n"
+      "s_and_saveexec_b64 %[sv], %[mw]\n"
+      "v_lshl_add_u32 v92, %[cur], 4, %[base]\n"
+      "v_add_u32_e32 v93, %[ox], v92\n"
+      "ds_read_b128 v[80:83], v93\n"
+      "v_add_u32_e32 v93, %[oy], v92\n"
+      "ds_read_b128 v[84:87], v93\n"
+      "v_add_u32_e32 v93, %[oz], v92\n"
+      "ds_read_b128 v[88:91], v93\n"
+      "ds_read_b64 v[92:93], v92 offset:96\n"
+      "s_waitcnt lgkmcnt(3)\n"
+      "v_pk_fma_f32 v[80:81], v[80:81], %[mx], %[ax] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_pk_fma_f32 v[82:83], v[82:83], %[mx], %[ax] op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_pk_fma_f32 v[84:85], v[84:85], %[my], %[ay] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_pk_fma_f32 v[86:87], v[86:87], %[my], %[ay] op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_pk_fma_f32 v[88:89], v[88:89], %[mz], %[az] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_pk_fma_f32 v[90:91], v[90:91], %[mz], %[az] op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_max_f32_e32 v80, v80, v84\n"   // entry distances: left child in v80, right in v81
+      "v_max_f32_e32 v81, v81, v85\n"
+      "v_min_f32_e32 v82, v82, v86\n"   // exit distances: left v82, right v83
+      "v_min_f32_e32 v83, v83, v87\n"
+      "v_max3_f32 v80, v80, v88, 0\n"
+      "v_max3_f32 v81, v81, v89, 0\n"
+      "v_min3_f32 v82, v82, v90, %[tmax]\n"
+      "v_min3_f32 v83, v83, v91, %[tmax]\n"
+      "v_cmp_le_f32_e32 vcc, v80, v82\n"         // hl
+      "v_cmp_le_f32_e64 %[mb], v81, v83\n"       // hr
+      "v_cmp_le_f32_e64 %[mc], v80, v81\n"       // left_first
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_and_b64 %[mt], vcc, %[mb]\n"            // both hit: push the farther child
+      "s_mov_b64 exec, %[mt]\n"
+      "ds_write_b16 %[sp], %[top]\n"
+      "v_add_u32_e32 %[sp], %[stride], %[sp]\n"
+      "v_cndmask_b32_e64 %[top], v92, v93, %[mc]\n"
+      "s_and_b64 %[mt], vcc, %[mc]\n"
+      "s_andn2_b64 %[mt], %[mb], %[mt]\n"        // take_right = hr & !(hl & left_first)
+      "s_mov_b64 exec, %[mw]\n"
+      "v_cndmask_b32_e64 %[cur], v92, v93, %[mt]\n"
+      "s_or_b64 %[mt], vcc, %[mb]\n"
+      "s_andn2_b64 exec, %[mw], %[mt]\n"         // neither hit: pop
+      "v_mov_b32_e32 %[cur], %[top]\n"
+      "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n"
+      "ds_read_i16 %[top], %[sp]\n"
+      "s_mov_b64 exec, %[sv]\n"
+      "s_branch 1b\n"
+      "2:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      : [cur] "+v"(ts.cur), [sp] "+v"(ts.sp), [top] "+v"(ts.top), [mw] "=&s"(m_walk), [sv] "=&s"(m_save), [mb] "=&s"(m_hr),
+        [mc] "=&s"(m_lf), [mt] "=&s"(m_t), [nw] "=&s"(n_walk)
+      : [need] "s"(need), [base] "s"(base), [stride] "s"(stride_bytes), [ox] "v"(ts.s.ox), [oy] "v"(ts.s.oy), [oz] "v"(ts.s.oz),
+        [mx] "v"(ts.s.mx), [my] "v"(ts.s.my), [mz] "v"(ts.s.mz), [ax] "v"(ts.s.ax), [ay] "v"(ts.s.ay), [az] "v"(ts.s.az),
+        [tmax] "v"(ts.tmax_w)
+      : "vcc", "scc", "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93");
+}
 // One primitive against the ray: on a hit closer than the best so far, the best hit becomes this one.
 template <class Acc>
 __device__ __forceinline__ void prim_test(const Acc& acc, TravState& ts, int32_t pi, uint32_t features, d3 o, d3 d, double time,
@@ -869,9 +970,13 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
   while (ts.cur != kDone) {
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();
-    while (ts.cur >= 0) {
-      if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
-      node_step(acc, ts, stack, stride);
+    if constexpr (RT_ASM_NODE_LOOP && !COUNT && !Acc::kWide && Acc::kSlabLds && sizeof(StackT) == 2) {
+      node_loop_slab16(acc, ts, stride * 2, 1u);
+    } else {
+      while (ts.cur >= 0) {
+        if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
+        node_step(acc, ts, stack, stride);
+      }
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
     if (ts.cur != kDone) {
@@ -905,17 +1010,21 @@ __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, b
     const uint32_t need = (m_node != m_busy) ? kn : 1u;
     uint64_t t0 = 0;
     if (COUNT) t0 = now_cycles();
-    while ((uint32_t)__popcll(m_node) >= need) {
-      if (at_node) {
-        if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
-        node_step(acc, ts, stack, stride);
-      } else if (COUNT) {
-        if (!participating) cnt->idle_free++;
-        else if (ts.cur == kDone) cnt->idle_done++;
-        else cnt->idle_leaf++;
+    if constexpr (RT_ASM_NODE_LOOP && !COUNT && !Acc::kWide && Acc::kSlabLds && sizeof(StackT) == 2) {
+      node_loop_slab16(acc, ts, stride * 2, need);
+    } else {
+      while ((uint32_t)__popcll(m_node) >= need) {
+        if (at_node) {
+          if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
+          node_step(acc, ts, stack, stride);
+        } else if (COUNT) {
+          if (!participating) cnt->idle_free++;
+          else if (ts.cur == kDone) cnt->idle_done++;
+          else cnt->idle_leaf++;
+        }
+        at_node = ts.cur >= 0;
+        m_node = wave_ballot(at_node);
       }
-      at_node = ts.cur >= 0;
-      m_node = wave_ballot(at_node);
     }
     if (COUNT) { uint64_t t1 = now_cycles(); cnt->t_nodes += (float)(t1 - t0) * wave_share(); t0 = t1; }
     if (ts.cur < 0 && ts.cur != kDone) {
@@ -1019,11 +1128,13 @@ __device__ __forceinline__ void noise_corners_dev(TabT table, int32_t ix, int32_
     c[k] = noise_value(xor4(xor4(tx[dx], ty[dy]), tz[dy * 2 + dz]));
   }
 }
-__device__ __forceinline__ int32_t sat_i32(double v) {  // Rust `as i32`
-  if (!(v == v)) return 0;
-  if (v <= -2147483648.0) return INT32_MIN;
-  if (v >= 2147483647.0) return INT32_MAX;
-  return (int32_t)v;
+// Rust `as i32`: saturating, NaN -> 0 — which is exactly what v_cvt_i32_f64 does (out-of-range values and infinities
+// saturate, NaN converts to 0).  The C++ cast is undefined out of range, so spelled out it was three compares and
+// three branches per coordinate, three coordinates per checker level.
+__device__ __forceinline__ int32_t sat_i32(double v) {
+  int32_t r;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+  return r;
 }
 __device__ __forceinline__ double rem_euclid1(double a) {  // f64::rem_euclid(1.0)
   double r = a - trunc(a);  // == fmod(a, 1.0) exactly

@@ -399,16 +399,12 @@ __device__ __forceinline__ void cursor_store(LdsSched* sched, uint32_t hi, uint3
 // Radiance channel -> fixed point.  The two things that make a sample reach the frame differently from what was
 // computed are counted (rt_stats.samples_nan / samples_clamped; `anomalies` = the render's ray counter block: [1] NaN
 // channels, [2] clamped channels): rare by construction, so each is a device atomic on the spot.
+// v_med3_f32 does the whole clamp: med3(v, 0, 2^20) is 0 for negatives and — a NaN operand makes med3 return the
+// minimum of the others — for NaN; the counting is a branch that is practically never taken.
 __device__ __forceinline__ unsigned long long to_fix(float v, float scale, unsigned long long* anomalies) {
-  if (!(v > 0.f)) {
-    if (v != v) atomicAdd(anomalies + 1, 1ull);
-    return 0ull;
-  }
-  if (v > RT_FIX_CLAMP) {
-    atomicAdd(anomalies + 2, 1ull);
-    v = RT_FIX_CLAMP;
-  }
-  return (unsigned long long)(v * scale);
+  const float c = __builtin_amdgcn_fmed3f(v, 0.f, RT_FIX_CLAMP);
+  if (!(v <= RT_FIX_CLAMP)) atomicAdd(anomalies + (v != v ? 1 : 2), 1ull);
+  return (unsigned long long)(c * scale);
 }
 
 // camera block and (single frames) the one-entry frame table travel as kernel arguments into their device slots:

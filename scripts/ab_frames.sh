@@ -2,7 +2,7 @@
 # scripts/ab_frames.sh REF "lib1 lib2 ..." [key=value ...]: small frames of every scene type under ab/librt_REF.so and under
 # each other build; codegen-only changes must give BIT-IDENTICAL frames (prints equal / differing per scene and build).
 REF=$1; LIBS=$2; shift 2
-SCENES="book_cover:200:16 cornell_box:160:16 cornell_smoke:160:16 final_scene_small:160:16 final_scene:240:8 earth:160:16 something_blocky:160:16 composition:160:16"
+SCENES="book_cover:200:16 cornell_box:160:16 cornell_smoke:160:16 final_scene_small:160:16 final_scene:240:9 earth:160:16 something_blocky:160:16 composition:160:16"
 mkdir -p gpurun_out/abf
 for L in $REF $LIBS; do
   for S in $SCENES; do
