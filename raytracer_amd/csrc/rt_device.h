@@ -130,6 +130,13 @@ struct Hits {
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1, uint32_t out[4]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the key is wave-uniform: its ten bumped values are two scalar adds per round HERE.  Left to itself the compiler
+  // hoists all eighteen out of the render loop, runs out of SGPRs and reads them back with a v_readlane each.
+  k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
+  k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k1);
+  asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
   for (int r = 0; r < 10; r++) {
     uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
@@ -1195,11 +1202,17 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
 }
 
 // ----------------------------------------------------------------------------------------------- sampling
+// Square roots of the SAMPLING code (directions on the unit sphere, lens disk, refraction): the bare v_sqrt_f32 (1 ulp),
+// like the v_sin / v_cos beside them; sqrtf() expands to 14 instructions of correction and denormal scaling.
+#ifndef RT_RAW_SQRT
+#define RT_RAW_SQRT 1
+#endif
+__device__ __forceinline__ float samp_sqrt(float x) { return RT_RAW_SQRT ? __builtin_amdgcn_sqrtf(x) : __builtin_sqrtf(x); }
 // vec3.rs:39-47 — uniform point on the unit sphere (theta uniform, z uniform).  v_sin/v_cos take revolutions.
 __device__ __forceinline__ f3 sample_unit_sphere(uint32_t r0, uint32_t r1) {
   float u = u01f(r0);
   float z = 2.f * u01f(r1) - 1.f;
-  float r = __builtin_sqrtf(fmaxf(0.f, 1.f - z * z));
+  float r = samp_sqrt(fmaxf(0.f, 1.f - z * z));
   return {r * __builtin_amdgcn_cosf(u), r * __builtin_amdgcn_sinf(u), z};
 }
 
@@ -1216,9 +1229,11 @@ __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t j, uint
   {
 #pragma clang fp contract(off)
     if (cam.sampler_kind == 0u) {  // Uniform(n): fixed grid, offset as in mod.rs:153-157
-      uint32_t n = cam.sampler_n;
-      uint32_t yi = s / n, xi = s - yi * n;
       const double interval = cam.grid_interval, offset = cam.grid_offset;
+      // s / n without the 22-instruction integer division: (s + 0.5) * (1/n) is at least 0.5/n away from an integer, far
+      // more than its f64 rounding error for any 32-bit s and n <= 65535 — the quotient is exact
+      uint32_t n = cam.sampler_n;
+      uint32_t yi = (uint32_t)(((double)s + 0.5) * interval), xi = s - yi * n;
       dy = (double)j + (double)yi * interval - offset;
       dx = (double)i + (double)xi * interval - offset;
     } else {  // Random(n): dy then dx uniform in [-0.5, 0.5) (mod.rs:166-167)
@@ -1231,7 +1246,7 @@ __device__ __forceinline__ void generate_ray(const Camera& cam, uint32_t j, uint
       o = {cam.center[0], cam.center[1], cam.center[2]};
     } else {
       // uniform point in the unit disk (same distribution as the rejection loop of vec3.rs:48-59)
-      float rr = __builtin_sqrtf(u01f(r[0]));
+      float rr = samp_sqrt(u01f(r[0]));
       float u = u01f(r[1]);
       double lx = (double)(rr * __builtin_amdgcn_cosf(u)), ly = (double)(rr * __builtin_amdgcn_sinf(u));
       o = {cam.center[0] + cam.dfu[0] * lx + cam.dfv[0] * ly, cam.center[1] + cam.dfu[1] * lx + cam.dfv[1] * ly,
@@ -1323,7 +1338,7 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
     float ratio = h.front ? __builtin_amdgcn_rcpf(M.ior) : M.ior;
     f3 ud = normalize(tof(d));
     float cos_t = fminf(-dot(ud, n), 1.0f);
-    float sin_t = __builtin_sqrtf(fmaxf(0.f, 1.0f - cos_t * cos_t));
+    float sin_t = samp_sqrt(fmaxf(0.f, 1.0f - cos_t * cos_t));
     bool cannot = ratio * sin_t > 1.0f;
     float r0 = (1.f - ratio) * __builtin_amdgcn_rcpf(1.f + ratio);
     r0 = r0 * r0;
@@ -1333,7 +1348,7 @@ __device__ __forceinline__ ShadeOut shade(const Scene& sc, const Acc& acc, const
       dir = ud - (2.0f * dot(ud, n)) * n;
     } else {  // refract (materials.rs:131-136)
       f3 perp = ratio * (ud + cos_t * n);
-      float par = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(perp, perp)));
+      float par = -samp_sqrt(__builtin_fabsf(1.0f - dot(perp, perp)));
       dir = perp + par * n;
     }
     att = {1.f, 1.f, 1.f};
