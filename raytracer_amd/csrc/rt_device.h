@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #define RT_BLOCK 256
 #define RT_STACK_DEPTH 32  // the host BVH builder guarantees tree depth < RT_STACK_DEPTH
 #define RT_TMIN 0.000001   // src/camera/mod.rs:198
@@ -490,7 +492,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // without its range scaling and class tests: 11 instructions instead of 19.  Arguments below 1e-300 (a discriminant
 // that is exactly 0: a tangent ray) give 1e-150 instead of 0.
 __device__ __forceinline__ double fast_sqrt_nonneg(double x) {
-  x = __builtin_fmax(x, 1e-300);
+  asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(x), "s"(1e-300));  // (fmax() would canonicalise x first: one more v_max_f64)
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   const double r = __builtin_fma(-h, g, 0.5);
@@ -798,6 +800,9 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
 #ifndef RT_ASM_NODE_LOOP
 #define RT_ASM_NODE_LOOP 1
 #endif
+#ifndef RT_ASM_TRAVERSAL
+#define RT_ASM_TRAVERSAL 1
+#endif
 template <class Acc>
 __device__ __forceinline__ void node_loop_slab16(const Acc& acc, TravState& ts, int stride_bytes, uint32_t need) {
   const uint32_t base = (uint32_t)lds_addr(acc.nodes);
@@ -864,6 +869,205 @@ __device__ __forceinline__ void node_loop_slab16(const Acc& acc, TravState& ts, 
         [mx] "v"(ts.s.mx), [my] "v"(ts.s.my), [mz] "v"(ts.s.mz), [ax] "v"(ts.s.ax), [ay] "v"(ts.s.ay), [az] "v"(ts.s.az),
         [tmax] "v"(ts.tmax_w)
       : "vcc", "scc", "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93");
+}
+// The WHOLE resumable traversal of a spheres-only LDS-resident scene (SlabLdsAcc, 16-bit stack) as one asm statement:
+// traverse_resume()'s loop — busy / at-node ballots, the inner-node loop above, the f64 sphere test of
+// sphere_hit() for the lanes at a leaf, the pop — with the same operations in the same order (every f64 operation is
+// the one the compiler emits for the C++ form, contraction off: frames stay bit-identical to the C++ traversal, which
+// the partner workgroups and the parity probes still run), but without the copies the compiler keeps between the two
+// loop levels (cur, sp, top, best_t each lived in two registers: ~13 v_mov per leaf round) and with the sphere test's
+// temporaries in place.
+// Named registers: VGPR temporaries v66..v93, SGPR temporaries s80..s97.
+//   node step   qx v[80:83]  qy v[84:87]  qz v[88:91]  links / address v[92:93]
+//   leaf test   centre -> oc v[66:71]   r -> r^2 -> a*surface v[72:73]   type v74   prim v75   address v76
+//               alignment v[78:79]   products / root2 v[80:81]   disc v[84:85]   sqrt g v[86:87] h v[88:89] tmp v[90:91]   root v[92:93]
+//   s[80:81] at-node mask   s[82:83] saved exec (step / leaf)   s[84:85] s[86:87] s[88:89] lane masks   s90 count   s91 need
+//   s92 node base   s93 sphere base   s[94:95] tmin   s[96:97] 1e-300   s98 the "finished" marker
+// Hazards handled by hand: s_nop after v_rsq_f64 (gfx940 trans forwarding), >= 2 instructions between a v_cmp and a
+// v_cndmask that reads its mask, LDS completes in order (lgkmcnt arithmetic as in node_loop_slab16).
+template <int STRIDE_BYTES>
+__device__ __forceinline__ void trav_resume_spheres_asm(const SlabLdsAcc& acc, TravState& ts, d3 o, d3 d, double time, uint32_t min_busy,
+                                                        uint32_t kn) {
+  // (wave-uniform by construction; said explicitly so that the "s" operands are SGPRs in every instantiation)
+  const uint32_t bases = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)((uint32_t)lds_addr(acc.nodes) | ((uint32_t)lds_addr(acc.spheres) << 16)));  // LDS addresses < 64 Ki
+  min_busy = (uint32_t)__builtin_amdgcn_readfirstlane((int)min_busy);
+  kn = (uint32_t)__builtin_amdgcn_readfirstlane((int)kn);
+  const double omt = 1. - time;  // geometry.rs:108
+  asm volatile(
+      "s_and_b32 s92, %[bases], 0xffff\n"
+      "s_lshr_b32 s93, %[bases], 16\n"
+      "s_mov_b32 s94, 0xa0b5ed8d\n"  // RT_TMIN = 1e-6
+      "s_mov_b32 s95, 0x3eb0c6f7\n"
+      "s_mov_b32 s96, 0xc2f8f359\n"  // 1e-300
+      "s_mov_b32 s97, 0x01a56e1f\n"
+      "s_mov_b32 s98, 0xffff8000\n"  // TravDone<int16_t>::v
+      "s_waitcnt lgkmcnt(0)\n"
+      // ---- while at least min_busy lanes are unfinished
+      "10:\n"
+      "v_cmp_ne_u32_e32 vcc, 0xffff8000, %[cur]\n"
+      "s_bcnt1_i32_b64 s90, vcc\n"
+      "s_cmp_lt_u32 s90, %[minbusy]\n"
+      "s_cbranch_scc1 19f\n"
+      "v_cmp_lt_i32_e64 s[80:81], -1, %[cur]\n"
+      "s_cmp_lg_u64 s[80:81], vcc\n"
+      "s_cselect_b32 s91, %[kn], 1\n"  // leave the node loop early only while some lane waits at a leaf
+      "s_branch 12f\n"
+      // ---- inner-node loop (node_loop_slab16)
+      "11:\n"
+      "v_cmp_lt_i32_e64 s[80:81], -1, %[cur]\n"
+      "12:\n"
+      "s_bcnt1_i32_b64 s90, s[80:81]\n"
+      "s_cmp_lt_u32 s90, s91\n"
+      "s_cbranch_scc1 13f\n"
+      "s_and_saveexec_b64 s[82:83], s[80:81]\n"
+      "v_lshl_add_u32 v92, %[cur], 4, s92\n"
+      "v_add_u32_e32 v93, %[ox], v92\n"
+      "ds_read_b128 v[80:83], v93\n"
+      "v_add_u32_e32 v93, %[oy], v92\n"
+      "ds_read_b128 v[84:87], v93\n"
+      "v_add_u32_e32 v93, %[oz], v92\n"
+      "ds_read_b128 v[88:91], v93\n"
+      "ds_read_b64 v[92:93], v92 offset:96\n"
+      "s_waitcnt lgkmcnt(3)\n"
+      "v_pk_fma_f32 v[80:81], v[80:81], %[mx], %[ax] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_pk_fma_f32 v[82:83], v[82:83], %[mx], %[ax] op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "s_waitcnt lgkmcnt(2)\n"
+      "v_pk_fma_f32 v[84:85], v[84:85], %[my], %[ay] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_pk_fma_f32 v[86:87], v[86:87], %[my], %[ay] op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "s_waitcnt lgkmcnt(1)\n"
+      "v_pk_fma_f32 v[88:89], v[88:89], %[mz], %[az] op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_pk_fma_f32 v[90:91], v[90:91], %[mz], %[az] op_sel:[0,1,1] op_sel_hi:[1,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n"
+      "v_max_f32_e32 v80, v80, v84\n"
+      "v_max_f32_e32 v81, v81, v85\n"
+      "v_min_f32_e32 v82, v82, v86\n"
+      "v_min_f32_e32 v83, v83, v87\n"
+      "v_max3_f32 v80, v80, v88, 0\n"
+      "v_max3_f32 v81, v81, v89, 0\n"
+      "v_min3_f32 v82, v82, v90, %[tmax]\n"
+      "v_min3_f32 v83, v83, v91, %[tmax]\n"
+      "v_cmp_le_f32_e32 vcc, v80, v82\n"
+      "v_cmp_le_f32_e64 s[84:85], v81, v83\n"
+      "v_cmp_le_f32_e64 s[86:87], v80, v81\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_and_b64 s[88:89], vcc, s[84:85]\n"
+      "s_mov_b64 exec, s[88:89]\n"
+      "ds_write_b16 %[sp], %[top]\n"
+      "v_add_u32_e32 %[sp], %[stride], %[sp]\n"
+      "v_cndmask_b32_e64 %[top], v92, v93, s[86:87]\n"
+      "s_and_b64 s[88:89], vcc, s[86:87]\n"
+      "s_andn2_b64 s[88:89], s[84:85], s[88:89]\n"
+      "s_mov_b64 exec, s[80:81]\n"
+      "v_cndmask_b32_e64 %[cur], v92, v93, s[88:89]\n"
+      "s_or_b64 s[88:89], vcc, s[84:85]\n"
+      "s_andn2_b64 exec, s[80:81], s[88:89]\n"
+      "v_mov_b32_e32 %[cur], %[top]\n"
+      "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n"
+      "ds_read_i16 %[top], %[sp]\n"
+      "s_mov_b64 exec, s[82:83]\n"
+      "s_branch 11b\n"
+      // ---- lanes at a leaf: sphere_hit() + pop
+      "13:\n"
+      "v_cmp_gt_i32_e32 vcc, 0, %[cur]\n"
+      "v_cmp_ne_u32_e64 s[84:85], s98, %[cur]\n"
+      "s_and_b64 s[84:85], vcc, s[84:85]\n"
+      "s_and_saveexec_b64 s[82:83], s[84:85]\n"
+      "s_cbranch_execz 18f\n"
+      "v_not_b32_e32 v75, %[cur]\n"
+      "v_lshl_add_u32 v76, v75, 6, s93\n"
+      "ds_read_b128 v[66:69], v76\n"
+      "ds_read2_b64 v[70:73], v76 offset0:2 offset1:6\n"
+      "ds_read_b32 v74, v76 offset:56\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_cmp_eq_u32_e32 vcc, 1, v74\n"
+      "s_and_saveexec_b64 s[86:87], vcc\n"
+      "s_cbranch_execz 14f\n"
+      "ds_read2_b64 v[80:83], v76 offset0:3 offset1:4\n"
+      "ds_read_b64 v[84:85], v76 offset:40\n"
+      "v_mul_f64 v[66:67], v[66:67], %[omt]\n"
+      "v_mul_f64 v[68:69], v[68:69], %[omt]\n"
+      "v_mul_f64 v[70:71], v[70:71], %[omt]\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "v_mul_f64 v[80:81], v[80:81], %[time]\n"
+      "v_mul_f64 v[82:83], v[82:83], %[time]\n"
+      "v_mul_f64 v[84:85], v[84:85], %[time]\n"
+      "v_add_f64 v[66:67], v[66:67], v[80:81]\n"
+      "v_add_f64 v[68:69], v[68:69], v[82:83]\n"
+      "v_add_f64 v[70:71], v[70:71], v[84:85]\n"
+      "14:\n"
+      "s_or_b64 exec, exec, s[86:87]\n"
+      "v_add_f64 v[66:67], %[o_x], -v[66:67]\n"
+      "v_add_f64 v[68:69], %[o_y], -v[68:69]\n"
+      "v_add_f64 v[70:71], %[o_z], -v[70:71]\n"
+      "v_mul_f64 v[78:79], %[d_x], v[66:67]\n"
+      "v_mul_f64 v[80:81], %[d_y], v[68:69]\n"
+      "v_mul_f64 v[66:67], v[66:67], v[66:67]\n"
+      "v_mul_f64 v[68:69], v[68:69], v[68:69]\n"
+      "v_add_f64 v[66:67], v[66:67], v[68:69]\n"
+      "v_mul_f64 v[68:69], v[70:71], v[70:71]\n"
+      "v_add_f64 v[78:79], v[78:79], v[80:81]\n"
+      "v_mul_f64 v[80:81], %[d_z], v[70:71]\n"
+      "v_add_f64 v[66:67], v[66:67], v[68:69]\n"
+      "v_mul_f64 v[72:73], v[72:73], v[72:73]\n"
+      "v_add_f64 v[78:79], v[78:79], v[80:81]\n"      // alignment
+      "v_add_f64 v[72:73], v[66:67], -v[72:73]\n"     // surface
+      "v_mul_f64 v[66:67], v[78:79], v[78:79]\n"
+      "v_mul_f64 v[72:73], %[a], v[72:73]\n"
+      "v_add_f64 v[84:85], v[66:67], -v[72:73]\n"     // discriminant
+      "v_cmp_ngt_f64_e32 vcc, 0, v[84:85]\n"
+      "s_and_saveexec_b64 s[86:87], vcc\n"
+      "s_cbranch_execz 17f\n"
+      "v_max_f64 v[84:85], v[84:85], s[96:97]\n"      // fast_sqrt_nonneg()
+      "v_rsq_f64_e32 v[88:89], v[84:85]\n"
+      "s_nop 0\n"
+      "v_mul_f64 v[86:87], v[84:85], v[88:89]\n"
+      "v_mul_f64 v[88:89], v[88:89], 0.5\n"
+      "v_fma_f64 v[90:91], -v[88:89], v[86:87], 0.5\n"
+      "v_fma_f64 v[86:87], v[86:87], v[90:91], v[86:87]\n"
+      "v_fma_f64 v[88:89], v[88:89], v[90:91], v[88:89]\n"
+      "v_fma_f64 v[90:91], -v[86:87], v[86:87], v[84:85]\n"
+      "v_fma_f64 v[86:87], v[90:91], v[88:89], v[86:87]\n"
+      "v_fma_f64 v[90:91], -v[86:87], v[86:87], v[84:85]\n"
+      "v_fma_f64 v[86:87], v[90:91], v[88:89], v[86:87]\n"
+      "v_add_f64 v[92:93], -v[78:79], -v[86:87]\n"    // nearer root
+      "v_mul_f64 v[92:93], %[inv_a], v[92:93]\n"
+      "v_cmp_lt_f64_e32 vcc, s[94:95], v[92:93]\n"
+      "v_cmp_lt_f64_e64 s[88:89], v[92:93], %[bt]\n"
+      "s_and_b64 s[88:89], vcc, s[88:89]\n"           // accepted at the nearer root
+      "s_mov_b64 s[80:81], exec\n"
+      "s_andn2_b64 exec, exec, s[88:89]\n"
+      "s_cbranch_execz 15f\n"
+      "v_add_f64 v[92:93], v[86:87], -v[78:79]\n"     // farther root
+      "v_mul_f64 v[92:93], %[inv_a], v[92:93]\n"
+      "v_cmp_lt_f64_e32 vcc, s[94:95], v[92:93]\n"
+      "v_cmp_lt_f64_e64 s[80:81], v[92:93], %[bt]\n"
+      "s_and_b64 s[80:81], vcc, s[80:81]\n"
+      "s_or_b64 s[88:89], s[88:89], s[80:81]\n"
+      "15:\n"
+      "s_mov_b64 exec, s[88:89]\n"                    // lanes with a new best hit
+      "v_mov_b64_e32 %[bt], v[92:93]\n"
+      "v_mov_b32_e32 %[bp], v75\n"
+      "v_cvt_f32_f64_e32 v90, v[92:93]\n"
+      "v_mov_b32_e32 v91, 0x0da24260\n"               // 1e-30f
+      "v_fmamk_f32 %[tmax], v90, 0x3f800012, v91\n"   // widen_tmax()
+      "17:\n"
+      "s_mov_b64 exec, s[84:85]\n"                    // every lane that was at a leaf pops
+      "v_mov_b32_e32 %[cur], %[top]\n"
+      "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n"
+      "ds_read_i16 %[top], %[sp]\n"
+      "18:\n"
+      "s_mov_b64 exec, s[82:83]\n"
+      "s_branch 10b\n"
+      "19:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      : [cur] "+v"(ts.cur), [sp] "+v"(ts.sp), [top] "+v"(ts.top), [bp] "+v"(ts.best_prim), [bt] "+v"(ts.best_t), [tmax] "+v"(ts.tmax_w)
+      : [minbusy] "s"(min_busy), [kn] "s"(kn), [bases] "s"(bases), [stride] "n"(STRIDE_BYTES), [ox] "v"(ts.s.ox), [oy] "v"(ts.s.oy),
+        [oz] "v"(ts.s.oz), [mx] "v"(ts.s.mx), [my] "v"(ts.s.my), [mz] "v"(ts.s.mz), [ax] "v"(ts.s.ax), [ay] "v"(ts.s.ay),
+        [az] "v"(ts.s.az), [o_x] "v"(o.x), [o_y] "v"(o.y), [o_z] "v"(o.z), [d_x] "v"(d.x), [d_y] "v"(d.y), [d_z] "v"(d.z),
+        [a] "v"(ts.a), [inv_a] "v"(ts.inv_a), [time] "v"(time), [omt] "v"(omt)
+      : "vcc", "scc", "memory", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v78", "v79", "v80", "v81",
+        "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "s80", "s81", "s82", "s83", "s84", "s85",
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98");
 }
 // One primitive against the ray: on a hit closer than the best so far, the best hit becomes this one.
 template <class Acc>
@@ -1003,12 +1207,16 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
 // unfinished (min_busy = 1: run everything to completion).  Inside, the inner-node loop is left as soon as fewer
 // than `kn` lanes still walk inner nodes while some lane waits at a leaf (kn = 1: plain while-while).
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-template <class Acc, class StackT, bool COUNT>
+template <class Acc, class StackT, bool COUNT, int STRIDE = 0>  // STRIDE: `stride` as a compile-time value where the caller has one
 __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, bool participating, uint32_t features,
                                                 d3 o, d3 d, double time, double tmin, StackT* stack, int stride,
                                                 TravCounters* cnt, PathRng& rng, uint32_t min_busy, uint32_t kn) {
   constexpr int32_t kDone = TravDone<StackT>::v;
   if (!participating) ts.cur = kDone;  // lanes without a path: nothing to walk (keeps the loop predicates to one compare)
+  if constexpr (RT_ASM_TRAVERSAL && !COUNT && STRIDE > 0 && sizeof(StackT) == 2 && std::is_same<Acc, SlabLdsAcc>::value) {
+    trav_resume_spheres_asm<STRIDE * 2>(acc, ts, o, d, time, min_busy, kn);  // (tmin is RT_TMIN on every path that renders)
+    return;
+  }
   while (true) {
     const unsigned long long m_busy = wave_ballot(ts.cur != kDone);
     if ((uint32_t)__popcll(m_busy) < min_busy) break;

@@ -835,7 +835,7 @@ __device__ __forceinline__ void fused_body(const Scene& sc, const Camera* __rest
       if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, F, o, d, time, RT_TMIN, rng);  // the ground: all starting lanes at once
       // ---- traverse until fewer than kb lanes are unfinished (stragglers keep their progress and go on next round
       //      beside the re-launched lanes); when nothing new was launched, run to completion
-      traverse_resume<typename AccOf<KIND>::type, StackT, STATS>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
+      traverse_resume<typename AccOf<KIND>::type, StackT, STATS, BLOCK>(acc, ts, active, F, o, d, time, RT_TMIN, stack, BLOCK,
                                                                  &tc, rng, fresh ? fp.kb : 1u, fp.kn);
       t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
       const bool ready = active && t_cur == kDone;
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_probe(Scene sc, uint32_t features,
 // `kr` are free, a traversal round hands back when fewer than `kb` lanes are unfinished (stragglers resume next round
 // beside the re-launched lanes), the node loop exits below `kn` walkers.  The hit record carries the render path's own
 // f32 shading normal and front flag (shading_frame) instead of make_hit's f64 ones; u, v as the texture code gets them.
-template <int KIND, int BLOCK>
+template <int KIND, int BLOCK, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t features, const rt_ray* __restrict__ rays, uint32_t n,
                                                        rt_hit* __restrict__ out, uint32_t n_cached, uint32_t kb, uint32_t kn,
                                                        uint32_t kr, unsigned long long* __restrict__ trav_counters) {
@@ -1066,8 +1066,9 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
     ts.cur = t_cur; ts.sp = t_sp; ts.top = t_top; ts.best_prim = t_best_prim; ts.best_t = t_best_t;
     ts.tmax_w = widen_tmax(t_best_t);
     if (sc.n_global && starting) global_prims_test(acc, global_prims(sc), ts, features, o, d, time, RT_TMIN, rng);
-    traverse_resume<typename AccOf<KIND>::type, StackT, true>(acc, ts, active, features, o, d, time, RT_TMIN, stack, BLOCK, &tc,
-                                                              rng, fresh ? kb : 1u, kn);
+    // COUNT = false is the render kernels' instantiation exactly (for sphere scenes in LDS: the asm traversal)
+    traverse_resume<typename AccOf<KIND>::type, StackT, COUNT, BLOCK>(acc, ts, active, features, o, d, time, RT_TMIN, stack, BLOCK, &tc,
+                                                                      rng, fresh ? kb : 1u, kn);
     t_cur = ts.cur; t_sp = ts.sp; t_top = ts.top; t_best_prim = ts.best_prim; t_best_t = ts.best_t;
     const bool ready = active && t_cur == kDone;
     fresh = __ballot(ready) != 0ull;
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_fused(Scene sc, uint32_t featur
       active = false;
     }
   }
-  if (trav_counters) {
+  if (COUNT && trav_counters) {
     atomicAdd(&trav_counters[0], (unsigned long long)tc.nodes);
     atomicAdd(&trav_counters[1], (unsigned long long)tc.prims);
   }
@@ -1183,6 +1184,7 @@ struct rt_ctx {
   const unsigned long long* last_ray_total = nullptr;  // ray counter of the last render (rt_get_stats)
   const uint32_t* last_watchdog = nullptr;             // watchdog flag of the last fused render
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
+  int probe_count = 0;  // probe_tree 3 / 4: count node visits / primitive tests (instrumented traversal) instead of running the render kernels' own
   unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
   uint32_t* d_bins = nullptr;  // wavefront material binning: class totals [0..5], class cursors [8..13]
@@ -1434,6 +1436,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "probe_tree") {
     if (value < 0 || value > 4) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be in 0..4");
     ctx->probe_tree = (int)value;
+  } else if (k == "probe_count") {
+    ctx->probe_count = value ? 1 : 0;
   } else if (k == "fused_tail4" || k == "fused_tail2") {
     if (value < 0 || value > 400) return fail(ctx, RT_E_INVALID_ARG, k + " must be in 0..400 (per mille of the frame's rows)");
     (k == "fused_tail4" ? ctx->fused_tail4 : ctx->fused_tail2) = (int)value;
@@ -1920,7 +1924,7 @@ int rt_scene_upload(rt_ctx* ctx, const rt_scene_desc* desc, rt_scene** out) {
 template <int KIND, int BLOCK>
 static int launch_probe_kind(rt_ctx* ctx, const rt_scene* scene, const rt_ray* d_rays, uint32_t m, rt_hit* d_hits, size_t smem,
                              uint32_t n_cached) {
-  auto kern = k_probe_fused<KIND, BLOCK>;
+  auto kern = ctx->probe_count ? k_probe_fused<KIND, BLOCK, true> : k_probe_fused<KIND, BLOCK, false>;
   size_t& opted = ctx->fused_lds_opt_in[reinterpret_cast<const void*>(kern)];
   if (smem > opted) {
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
