@@ -35,7 +35,8 @@ struct __attribute__((aligned(64))) BvhNode {  // 64 B: both child boxes + child
 
 struct __attribute__((aligned(128))) Prim {  // 128 B
   // SPHERE / MOVING_SPHERE: f[0..2]=center0, f[3..5]=center1, f[6]=radius
-  // QUAD: f[0..2]=Q, f[3..5]=u, f[6..8]=v, f[9..11]=unit normal, f[12]=D, f[13]=1/|u x v|
+  // QUAD: f[0..2]=Q, f[3..5]=v x w, f[6..8]=w x u (w = u x v / |u x v|^2: alpha = (p - Q).(v x w), beta = (p - Q).(w x u)),
+  //       f[9..11]=unit normal, f[12]=D, f[13]=1/|u x v|
   // MEDIUM_SPHERE: f[0..2]=center, f[3]=f[12]=-1/density, f[6]=radius
   // MEDIUM_BOX: f[0..2]=corner, f[3..5],f[6..8],f[9..11]=edges / |edge|^2, f[12]=-1/density
   // AABOX (type 5, library-internal: six QUADs that form an axis-aligned box, merged at upload): f[0..2]=lo, f[3..5]=hi,
@@ -487,6 +488,17 @@ __device__ __forceinline__ double fast_rcp(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
+// n / d with the iteration of the compiler's own f64 division — v_rcp_f64, two Newton steps on the reciprocal, the
+// quotient and one residual correction — without v_div_scale / v_div_fmas / v_div_fixup around it: the same bits as
+// n / d whenever no operand or result sits near the ends of the exponent range (the scaling's only job) and d != 0.
+// The callers divide by direction components or plane normals of magnitude >= 1e-8.  9 instructions instead of 14.
+__device__ __forceinline__ double div_noscale(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double q = n * r;
+  return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
 // sqrt of a non-negative f64 with the iteration the compiler's own expansion uses (v_rsq_f64 start, two Goldschmidt
 // steps, two residual corrections: correctly rounded in practice, the same bits as __builtin_sqrt for x >= 1e-300)
 // without its range scaling and class tests: 11 instructions instead of 19.  Arguments below 1e-300 (a discriminant
@@ -538,16 +550,16 @@ __device__ __forceinline__ bool quad_hit(const Prim& P, d3 o, d3 d, double tmin,
   d3 n = {P.f[9], P.f[10], P.f[11]};
   double denom = n.x * d.x + n.y * d.y + n.z * d.z;
   if (__builtin_fabs(denom) < 1e-8) return false;
-  double t = (P.f[12] - (n.x * o.x + n.y * o.y + n.z * o.z)) / denom;  // true division: edge-on rays decide by the last ulp
+  double t = div_noscale(P.f[12] - (n.x * o.x + n.y * o.y + n.z * o.z), denom);  // the true quotient: edge-on rays decide by the last ulp
   if (!(tmin < t && t < tmax)) return false;
   d3 p = {o.x + t * d.x, o.y + t * d.y, o.z + t * d.z};
   d3 ph = {p.x - P.f[0], p.y - P.f[1], p.z - P.f[2]};
-  d3 u = {P.f[3], P.f[4], P.f[5]}, v = {P.f[6], P.f[7], P.f[8]};
-  d3 w = {n.x * P.f[13], n.y * P.f[13], n.z * P.f[13]};  // n_raw / (n_raw . n_raw)
-  d3 phxv = {ph.y * v.z - ph.z * v.y, ph.z * v.x - ph.x * v.z, ph.x * v.y - ph.y * v.x};
-  d3 uxph = {u.y * ph.z - u.z * ph.y, u.z * ph.x - u.x * ph.z, u.x * ph.y - u.y * ph.x};
-  double alpha = w.x * phxv.x + w.y * phxv.y + w.z * phxv.z;
-  double beta = w.x * uxph.x + w.y * uxph.y + w.z * uxph.z;
+  // planar coordinates: alpha = w.(ph x v), beta = w.(u x ph) with w = n_raw / (n_raw.n_raw) in the book's form — 31
+  // operations per candidate.  By the triple-product identity they are ph.(v x w) and ph.(w x u), and those two vectors
+  // are constants of the quad (rt_scene_upload stores them in place of u and v): six operations.  Equal up to rounding;
+  // a hit exactly on a quad's edge may go to the other side of the tie than in the cross-product form.
+  double alpha = __builtin_fma(P.f[5], ph.z, __builtin_fma(P.f[4], ph.y, P.f[3] * ph.x));
+  double beta = __builtin_fma(P.f[8], ph.z, __builtin_fma(P.f[7], ph.y, P.f[6] * ph.x));
   if (alpha < 0. || alpha > 1. || beta < 0. || beta > 1.) return false;
   t_out = t;
   if (ab) { ab[0] = alpha; ab[1] = beta; }
@@ -592,7 +604,7 @@ RT_AABOX_INLINE bool aabox_hit(const Prim& P, d3 blo, d3 bhi, d3 o, d3 d, const 
     const int a = f >> 1;
     const double plane = (f & 1) ? (a == 0 ? bhi.x : a == 1 ? bhi.y : bhi.z) : (a == 0 ? blo.x : a == 1 ? blo.y : blo.z);
     const double oa = a == 0 ? o.x : a == 1 ? o.y : o.z, da = a == 0 ? d.x : a == 1 ? d.y : d.z;
-    t = (plane - oa) / da;
+    t = div_noscale(plane - oa, da);
     if (tmin < t) break;
     f = fx;
   }

@@ -1589,8 +1589,12 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
       double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
       if (!(len > 0)) return fail(ctx, RT_E_INVALID_ARG, "prim " + std::to_string(i) + ": degenerate quad");
+      // w = n_raw / (n_raw . n_raw); the device evaluates alpha = (p - Q).(v x w), beta = (p - Q).(w x u) (quad_hit)
+      const double w[3] = {n[0] / (len * len), n[1] / (len * len), n[2] / (len * len)};
+      const double vxw[3] = {v[1] * w[2] - v[2] * w[1], v[2] * w[0] - v[0] * w[2], v[0] * w[1] - v[1] * w[0]};
+      const double wxu[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
       for (int a = 0; a < 3; a++) {
-        q.f[a] = Q[a]; q.f[3 + a] = u[a]; q.f[6 + a] = v[a]; q.f[9 + a] = n[a] / len;
+        q.f[a] = Q[a]; q.f[3 + a] = vxw[a]; q.f[6 + a] = wxu[a]; q.f[9 + a] = n[a] / len;
         double c[4] = {Q[a], Q[a] + u[a], Q[a] + v[a], Q[a] + u[a] + v[a]};
         b.lo[a] = std::fmin(std::fmin(c[0], c[1]), std::fmin(c[2], c[3]));
         b.hi[a] = std::fmax(std::fmax(c[0], c[1]), std::fmax(c[2], c[3]));
