@@ -193,7 +193,7 @@ def roofline_block(workload, wl, samples_per_launch, kernel_ms, stats, own=None,
     if pmc:
         der, cnt = pmc.get("derived", {}), pmc.get("counters", {})
         if "hbm_write_bytes" in der and "hbm_fetch_bytes_x2_upper" in der:
-            out["traffic"] = der["hbm_fetch_bytes_x2_upper"] + der["hbm_write_bytes"]
+            out["traffic"] = (der["hbm_fetch_bytes_x2_upper"] + der["hbm_write_bytes"]) * scale
             out["traffic_note"] = ("HBM bytes per launch (rocprofv3 FETCH_SIZE x2 upper bound + WRITE_SIZE, " + src +
                                    "); algorithmic output is W*H*12 B; scene and path state live in LDS / L2 / registers")
         if "SQ_INSTS_VALU" in cnt and der.get("valu_active_lane_fraction"):
@@ -550,7 +550,8 @@ def main():
                     "workload": r5.label(), "value": n5 / el5 / 1e6, "unit": "Msamples/s", "seconds": el5, "steps": 1,
                     "launches": C5_FULL_PASSES, "config_spp": r5.config_spp, "spp": r5.spp, "samples": n5, "rays": rays5,
                     "kernel_ms_total": k_ms5, "mean_linear_radiance": mean5, "mean_linear_radiance_16spp_frame": mean16,
-                    "roofline": roofline_block("c5", r5.wl, n5, k_ms5, {"rays": rays5, "paths": n5}, out["workloads"]["c5"]["roofline"].get("own_tree", {}).get("per_sample"))}
+                    "roofline": roofline_block("c5", r5.wl, n5, k_ms5, {"rays": rays5, "paths": n5}, out["workloads"]["c5"]["roofline"].get("own_tree", {}).get("per_sample"),
+                                               frame_samples=r16.W * r16.H * r16.spp)}  # (the PMC profile is that of the 16-spp frame)
                 if "cpu_baseline" in out["workloads"]["c5"]:
                     out["workloads"]["c5_full"]["gpu_over_cpu"] = n5 / el5 / 1e6 / out["workloads"]["c5"]["cpu_baseline"]["value"]
                 del acc5, p5, d16, r5, r16

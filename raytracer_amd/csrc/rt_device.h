@@ -295,6 +295,7 @@ struct GlobalAcc {
   static constexpr bool kPrimsInHbm = true;
   static constexpr bool kWide = false;
   static constexpr bool kSlabLds = false;  // 112-byte slab nodes in LDS (node_loop_slab16)
+  static constexpr bool kWideHalf = false;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -321,6 +322,7 @@ struct SphereAcc {
   static constexpr bool kPrimsInHbm = true;
   static constexpr bool kWide = false;
   static constexpr bool kSlabLds = false;  // 112-byte slab nodes in LDS (node_loop_slab16)
+  static constexpr bool kWideHalf = false;
   __device__ __forceinline__ GlobalTablePtr noise_table(const Scene& sc) const { return reinterpret_cast<GlobalTablePtr>(sc.noise_table); }
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
@@ -357,6 +359,7 @@ struct SlabLdsAcc {
   static constexpr bool kPrimsInHbm = false;
   static constexpr bool kWide = false;
   static constexpr bool kSlabLds = true;  // 112-byte slab nodes in LDS (node_loop_slab16)
+  static constexpr bool kWideHalf = false;
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -386,6 +389,7 @@ struct GenericLdsAcc {
   static constexpr bool kPrimsInHbm = false;
   static constexpr bool kWide = false;
   static constexpr bool kSlabLds = true;  // 112-byte slab nodes in LDS (node_loop_slab16)
+  static constexpr bool kWideHalf = false;
   __device__ __forceinline__ const Material* mats(const Scene& sc) const { return sc.mats; }
   __device__ __forceinline__ const Texture* texs(const Scene& sc) const { return sc.texs; }
   __device__ __forceinline__ LdsTablePtr noise_table(const Scene&) const { return noise; }
@@ -442,6 +446,7 @@ struct WideHalfAcc : Base {
   const uint4* cache;  // generic pointer into LDS
   int32_t n_cached;
   static constexpr bool kWide = true;
+  static constexpr bool kWideHalf = true;  // node_loop_wide16
   __device__ __forceinline__ int32_t root(int32_t r) const { return r >= 0 ? 0 : r; }
   __device__ __forceinline__ void wide_node(int32_t i, const SlabRay& s, float4& ex, float4& fx, float4& ey, float4& fy,
                                             float4& ez, float4& fz, int4& ch) const {
@@ -812,6 +817,11 @@ __device__ __forceinline__ void node_step(const Acc& acc, TravState& ts, StackT*
 #ifndef RT_ASM_NODE_LOOP
 #define RT_ASM_NODE_LOOP 1
 #endif
+// (the sphere-only wide instances run at 96 VGPRs beside the LDS-resident kernel — the partner workgroups — and have no
+// room for the loop's 28 named registers: 18 spilled VGPRs, C2 +0.7 %; they keep the compiled loop)
+#ifndef RT_ASM_WIDE_FOR
+#define RT_ASM_WIDE_FOR(Acc) (!Acc::kSpheresOnly)
+#endif
 #ifndef RT_ASM_TRAVERSAL
 #define RT_ASM_TRAVERSAL 1
 #endif
@@ -881,6 +891,138 @@ __device__ __forceinline__ void node_loop_slab16(const Acc& acc, TravState& ts, 
         [mx] "v"(ts.s.mx), [my] "v"(ts.s.my), [mz] "v"(ts.s.mz), [ax] "v"(ts.s.ax), [ay] "v"(ts.s.ay), [az] "v"(ts.s.az),
         [tmax] "v"(ts.tmax_w)
       : "vcc", "scc", "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93");
+}
+// The inner-node loop of the four-wide binary16 traversals (WideHalfAcc, 16-bit stacks: the HBM-resident render
+// instances and the partner workgroups) as one asm statement, like node_loop_slab16: the operations of node_step_wide()
+// on the same operands in the same order (same v_fma_mix_f32 / v_max3 / v_min3 per plane, the same five-exchange
+// network with strict `<` swaps, pushes farthest first) — results are bit-identical — with what the compiled form spends
+// around them removed: the LDS-or-global node address as a generic pointer (10 instructions -> 2: cached lanes read with
+// ds_read, the others with global_load off a scalar base), two register copies per push and three per pop, the copies
+// between the loop levels.  ~101 VALU per step instead of ~123.
+// Named registers: v60..v82 — node words A v[60:63] B v[64:67] C v[68:71] (x / y / z: lo01 lo23 hi01 hi23), links
+// v[72:75], entry planes by direction v[76:81] (exit planes stay in A / B / C's upper halves; v76 first holds the node's
+// address), +inf v82; the low halves of A / B / C hold the entry distances and scratch once the planes are selected, and
+// the sorting network renames into whatever is free.  s80..s98: masks, count.
+template <class Acc>
+__device__ __forceinline__ void node_loop_wide16(const Acc& acc, TravState& ts, int stride_bytes, uint32_t need) {
+  const uint32_t cache_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lds_addr(acc.cache));
+  const uint32_t n_cached = (uint32_t)__builtin_amdgcn_readfirstlane(acc.n_cached);
+  need = (uint32_t)__builtin_amdgcn_readfirstlane((int)need);
+  const SlabRay& r = ts.s;
+// one child: entry distance -> TN, exit distance -> v68, hit mask (entry <= exit) -> HIT; v69 is scratch
+#define RT_WIDE_CHILD(TN, HIT, EX, EY, EZ, FX, FY, FZ, SEL)                                                      \
+  "v_fma_mix_f32 " TN ", " EX ", %[ix], -%[nx] " SEL "\n"                                                      \
+  "v_fma_mix_f32 v69, " EY ", %[iy], -%[ny] " SEL "\n"                                                         \
+  "v_max_f32_e32 " TN ", " TN ", v69\n"                                                                        \
+  "v_fma_mix_f32 v69, " EZ ", %[iz], -%[nz] " SEL "\n"                                                         \
+  "v_max3_f32 " TN ", " TN ", v69, 0\n"                                                                        \
+  "v_fma_mix_f32 v68, " FX ", %[ixw], -%[ox] " SEL "\n"                                                        \
+  "v_fma_mix_f32 v69, " FY ", %[iyw], -%[oy] " SEL "\n"                                                        \
+  "v_min_f32_e32 v68, v68, v69\n"                                                                              \
+  "v_fma_mix_f32 v69, " FZ ", %[izw], -%[oz] " SEL "\n"                                                        \
+  "v_min3_f32 v68, v68, v69, %[tmax]\n"                                                                        \
+  "v_cmp_le_f32_e64 " HIT ", " TN ", v68\n"
+// compare-exchange of (distance, link) pairs: swap iff TJ < TI (strictly), results renamed into fresh registers
+#define RT_WIDE_CAS(M, TI, TJ, CI, CJ, TLO, THI, CLO, CHI) \
+  "v_cmp_lt_f32_e64 " M ", " TJ ", " TI "\n"                \
+  "v_min_f32_e32 " TLO ", " TI ", " TJ "\n"                 \
+  "v_max_f32_e32 " THI ", " TI ", " TJ "\n"                 \
+  "v_cndmask_b32_e64 " CLO ", " CI ", " CJ ", " M "\n"      \
+  "v_cndmask_b32_e64 " CHI ", " CJ ", " CI ", " M "\n"
+  asm volatile(
+      "v_cmp_gt_f32_e64 s[84:85], 0, %[ix]\n"  // direction negative on the axis (SlabRay::sx, sy, sz)
+      "v_cmp_gt_f32_e64 s[86:87], 0, %[iy]\n"
+      "v_cmp_gt_f32_e64 s[88:89], 0, %[iz]\n"
+      "v_mov_b32_e32 v82, 0x7f800000\n"
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+      "1:\n"
+      "v_cmp_lt_i32_e64 s[80:81], -1, %[cur]\n"
+      "s_bcnt1_i32_b64 s98, s[80:81]\n"
+      "s_cmp_lt_u32 s98, %[need]\n"
+      "s_cbranch_scc1 9f\n"
+      "s_and_saveexec_b64 s[82:83], s[80:81]\n"
+      // ---- the node's 64 bytes: from the LDS copy of the top of the tree, else from memory
+      "v_cmp_gt_i32_e32 vcc, %[ncached], %[cur]\n"
+      "s_and_b64 exec, s[80:81], vcc\n"
+      "v_lshl_add_u32 v76, %[cur], 6, %[cbase]\n"
+      "ds_read_b128 v[60:63], v76\n"
+      "ds_read_b128 v[64:67], v76 offset:16\n"
+      "ds_read_b128 v[68:71], v76 offset:32\n"
+      "ds_read_b128 v[72:75], v76 offset:48\n"
+      "s_andn2_b64 exec, s[80:81], vcc\n"
+      "s_cbranch_execz 2f\n"
+      "v_lshlrev_b32_e32 v76, 6, %[cur]\n"
+      "global_load_dwordx4 v[60:63], v76, %[nodes]\n"
+      "global_load_dwordx4 v[64:67], v76, %[nodes] offset:16\n"
+      "global_load_dwordx4 v[68:71], v76, %[nodes] offset:32\n"
+      "global_load_dwordx4 v[72:75], v76, %[nodes] offset:48\n"
+      "2:\n"
+      "s_mov_b64 exec, s[80:81]\n"
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+      // ---- entry / exit planes for the ray's direction
+      "v_cndmask_b32_e64 v76, v60, v62, s[84:85]\n"
+      "v_cndmask_b32_e64 v77, v61, v63, s[84:85]\n"
+      "v_cndmask_b32_e64 v62, v62, v60, s[84:85]\n"
+      "v_cndmask_b32_e64 v63, v63, v61, s[84:85]\n"
+      "v_cndmask_b32_e64 v78, v64, v66, s[86:87]\n"
+      "v_cndmask_b32_e64 v79, v65, v67, s[86:87]\n"
+      "v_cndmask_b32_e64 v66, v66, v64, s[86:87]\n"
+      "v_cndmask_b32_e64 v67, v67, v65, s[86:87]\n"
+      "v_cndmask_b32_e64 v80, v68, v70, s[88:89]\n"
+      "v_cndmask_b32_e64 v81, v69, v71, s[88:89]\n"
+      "v_cndmask_b32_e64 v70, v70, v68, s[88:89]\n"
+      "v_cndmask_b32_e64 v71, v71, v69, s[88:89]\n"
+      // ---- four slab tests: entry distances v60 v61 v64 v65 (the node words' low halves are free now), hit masks
+      RT_WIDE_CHILD("v60", "vcc", "v76", "v78", "v80", "v62", "v66", "v70", "op_sel_hi:[1,0,0]")
+      RT_WIDE_CHILD("v61", "s[90:91]", "v76", "v78", "v80", "v62", "v66", "v70", "op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+      RT_WIDE_CHILD("v64", "s[92:93]", "v77", "v79", "v81", "v63", "v67", "v71", "op_sel_hi:[1,0,0]")
+      RT_WIDE_CHILD("v65", "s[94:95]", "v77", "v79", "v81", "v63", "v67", "v71", "op_sel:[1,0,0] op_sel_hi:[1,0,0]")
+      "v_cndmask_b32_e32 v60, v82, v60, vcc\n"         // t[k] = hit ? entry distance : +inf
+      "v_cndmask_b32_e64 v61, v82, v61, s[90:91]\n"
+      "v_cndmask_b32_e64 v64, v82, v64, s[92:93]\n"
+      "v_cndmask_b32_e64 v65, v82, v65, s[94:95]\n"
+      // ---- sort by distance: (0,1) (2,3) (0,2) (1,3) (1,2), every result in a register that is free by then
+      RT_WIDE_CAS("s[90:91]", "v60", "v61", "v72", "v73", "v62", "v63", "v76", "v77")   // -> t v62 v63, c v76 v77
+      RT_WIDE_CAS("s[92:93]", "v64", "v65", "v74", "v75", "v66", "v67", "v78", "v79")   // -> t v66 v67, c v78 v79
+      RT_WIDE_CAS("s[90:91]", "v62", "v66", "v76", "v78", "v60", "v64", "v72", "v74")   // (0,2) -> t v60 v64, c v72 v74
+      RT_WIDE_CAS("s[92:93]", "v63", "v67", "v77", "v79", "v61", "v65", "v73", "v75")   // (1,3) -> t v61 v65, c v73 v75
+      RT_WIDE_CAS("s[90:91]", "v61", "v64", "v73", "v74", "v62", "v63", "v76", "v77")   // (1,2) -> t v62 v63, c v76 v77
+      // sorted: t = v60 v62 v63 v65, links = v72 v76 v77 v75
+      "v_cmp_lt_f32_e64 s[90:91], v65, v82\n"
+      "v_cmp_lt_f32_e64 s[92:93], v63, v82\n"
+      "v_cmp_lt_f32_e64 s[94:95], v62, v82\n"
+      "v_cmp_lt_f32_e32 vcc, v60, v82\n"
+      "s_mov_b64 exec, s[90:91]\n"                     // push the hit children, farthest first
+      "ds_write_b16 %[sp], %[top]\n"
+      "v_add_u32_e32 %[sp], %[stride], %[sp]\n"
+      "v_mov_b32_e32 %[top], v75\n"
+      "s_mov_b64 exec, s[92:93]\n"
+      "ds_write_b16 %[sp], %[top]\n"
+      "v_add_u32_e32 %[sp], %[stride], %[sp]\n"
+      "v_mov_b32_e32 %[top], v77\n"
+      "s_mov_b64 exec, s[94:95]\n"
+      "ds_write_b16 %[sp], %[top]\n"
+      "v_add_u32_e32 %[sp], %[stride], %[sp]\n"
+      "v_mov_b32_e32 %[top], v76\n"
+      "s_mov_b64 exec, s[80:81]\n"
+      "v_mov_b32_e32 %[cur], v72\n"                    // continue with the nearest ...
+      "s_andn2_b64 exec, s[80:81], vcc\n"
+      "v_mov_b32_e32 %[cur], %[top]\n"                 // ... or pop when nothing was hit
+      "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n"
+      "ds_read_i16 %[top], %[sp]\n"
+      "s_mov_b64 exec, s[82:83]\n"
+      "s_branch 1b\n"
+      "9:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      : [cur] "+v"(ts.cur), [sp] "+v"(ts.sp), [top] "+v"(ts.top)
+      : [need] "s"(need), [stride] "s"(stride_bytes), [ncached] "s"(n_cached), [cbase] "s"(cache_base), [nodes] "s"(acc.nodes4h),
+        [tmax] "v"(ts.tmax_w), [ix] "v"(r.mx.x), [ixw] "v"(r.mx.y), [iy] "v"(r.my.x), [iyw] "v"(r.my.y), [iz] "v"(r.mz.x),
+        [izw] "v"(r.mz.y), [nx] "v"(r.ax.x), [ox] "v"(r.ax.y), [ny] "v"(r.ay.x), [oy] "v"(r.ay.y), [nz] "v"(r.az.x), [oz] "v"(r.az.y)
+      : "vcc", "scc", "memory", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
+        "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
+        "s90", "s91", "s92", "s93", "s94", "s95", "s98");
+#undef RT_WIDE_CHILD
+#undef RT_WIDE_CAS
 }
 // The WHOLE resumable traversal of a spheres-only LDS-resident scene (SlabLdsAcc, 16-bit stack) as one asm statement:
 // traverse_resume()'s loop — busy / at-node ballots, the inner-node loop above, the f64 sphere test of
@@ -1195,6 +1337,8 @@ __device__ __forceinline__ HitInfo traverse(const Acc& acc, int32_t root, uint32
     if (COUNT) t0 = now_cycles();
     if constexpr (RT_ASM_NODE_LOOP && !COUNT && !Acc::kWide && Acc::kSlabLds && sizeof(StackT) == 2) {
       node_loop_slab16(acc, ts, stride * 2, 1u);
+    } else if constexpr (RT_ASM_NODE_LOOP && !COUNT && Acc::kWideHalf && RT_ASM_WIDE_FOR(Acc) && sizeof(StackT) == 2) {
+      node_loop_wide16(acc, ts, stride * 2, 1u);
     } else {
       while (ts.cur >= 0) {
         if (COUNT) { cnt->nodes++; cnt->wnodes += wave_share(); }
@@ -1239,6 +1383,8 @@ __device__ __forceinline__ void traverse_resume(const Acc& acc, TravState& ts, b
     if (COUNT) t0 = now_cycles();
     if constexpr (RT_ASM_NODE_LOOP && !COUNT && !Acc::kWide && Acc::kSlabLds && sizeof(StackT) == 2) {
       node_loop_slab16(acc, ts, stride * 2, need);
+    } else if constexpr (RT_ASM_NODE_LOOP && !COUNT && Acc::kWideHalf && RT_ASM_WIDE_FOR(Acc) && sizeof(StackT) == 2) {
+      node_loop_wide16(acc, ts, stride * 2, need);
     } else {
       while ((uint32_t)__popcll(m_node) >= need) {
         if (at_node) {

@@ -327,9 +327,12 @@ static_assert(sizeof(WgSched) % 16 == 0, "scheduler block keeps the LDS regions 
 #define RT_CUR_EXHAUSTED 0xFFFFFFFFu
 #define RT_FIX_CLAMP 1048576.0f  // 2^20: largest radiance channel a sample can add
 
-// workgroup size of the HBM-resident instances that carry the whole feature set (noise / image / medium code)
+// workgroup size of the HBM-resident instances that carry the whole feature set (noise / image / medium code).  768 threads
+// (3 waves per SIMD, 168 VGPRs) until the node loop became an asm statement: compiled, the 128-VGPR form spilled inside the
+// traversal loop.  Now the loop's registers are named, the spills that remain sit in the per-round and texture code, and
+// four waves win: final scene 41.7 -> 41.1 ms.
 #ifndef RT_HEAVY_BLOCK
-#define RT_HEAVY_BLOCK 768
+#define RT_HEAVY_BLOCK 1024
 #endif
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5,
        KIND_GENERIC_WIDE_HALF = 6, KIND_SPHERES_WIDE_HALF = 7 };
