@@ -663,7 +663,7 @@ __device__ __forceinline__ bool medium_hit(const Prim& P, d3 o, d3 d, double a, 
   if (t2 > tmax) t2 = tmax;
   if (t1 >= t2) return false;
   if (t1 < 0.) t1 = 0.;
-  double len = __builtin_sqrt(a);
+  double len = fast_sqrt_nonneg(a);
   double dist_inside = (t2 - t1) * len;
   // free path -ln(u)/density: u is a 32-bit draw, so the hardware f32 logarithm (v_log_f32, ~1 ulp) loses nothing
   double hit_distance = neg_inv_density * (double)(__builtin_amdgcn_logf(u01f(rng_next(rng))) * 0.69314718056f);

@@ -15,3 +15,5 @@ timeout -k 10 120 python scripts/fused_stats.py 100 --stats > gpurun_out/r3_stat
 timeout -k 10 600 python bench.py > gpurun_out/r3_final_bench.json 2> gpurun_out/r3_final_bench.err
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --rehearse --steps 3 --warmup 1 --no-cpu-baseline --no-workloads --no-strong-workloads --no-c5-full > gpurun_out/r3_rehearse.json 2> gpurun_out/r3_rehearse.err
 echo done
+# afterwards, in the container: python scripts/summarize_profile.py r03_c2 c2; ... r03_c5 c5; ... r03_c4 c4  (the second
+# argument names the pmc_<workload>_latest.json that bench.py reads), commit profiles/, then re-run bench.py for the line
