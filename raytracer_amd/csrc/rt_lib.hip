@@ -2699,12 +2699,14 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out) {
       const int frc = rt_internal_frame_status(ctx);
       if (frc != RT_OK) return frc;
     }
+    ctx->timing_pending = false;
+  }
+  {  // probe counters: rt_intersect is synchronous, so they are current whether or not a render is pending
     unsigned long long trav[2] = {0, 0};
     HIP_TRY(ctx, hipMemcpy(trav, ctx->d_trav, sizeof(trav), hipMemcpyDeviceToHost));
     ctx->stats.probe_rays = ctx->probe_rays;
     ctx->stats.probe_node_visits = trav[0];
     ctx->stats.probe_prim_tests = trav[1];
-    ctx->timing_pending = false;
   }
   *out = ctx->stats;
   out->lib_alloc_calls = rti::g_alloc_calls.load();

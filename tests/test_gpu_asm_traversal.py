@@ -1,0 +1,110 @@
+"""The hand-scheduled asm traversals against their compiled C++ twins, through the C ABI.
+
+Round 3 moved the loops in which a frame's time is spent into asm statements (rt_device.h: trav_resume_spheres_asm —
+the whole resumable traversal of LDS-resident sphere scenes; node_loop_slab16 — the node loop of LDS-resident general
+scenes; node_loop_wide16 — the node loop of the four-wide binary16 tree).  Each claims to execute the operations of
+the C++ form it replaces (node_step, sphere_hit, node_step_wide) on the same operands in the same order.  The C++ forms
+are still compiled: the instrumented kernels (option fused_stats = 1) and the counting probes (probe_count = 1) run
+them.  So the claim is checkable inside this suite, on whatever box it runs: frames and hits must agree BIT FOR BIT
+between the two (the same bar as the other variant tests: test_c2_kernel_variants_agree_at_full_size)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+
+pytestmark = pytest.mark.gpu
+
+ASPECT = 16.0 / 9.0
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ra.Context(0)
+    yield c
+    c.close()
+
+
+def earth_texels():
+    from golden_data import load_earth_rgba
+    return load_earth_rgba()
+
+
+# scene -> which asm path its render kernel takes
+SCENES = [("book_cover", 320, 16, "whole sphere traversal (trav_resume_spheres_asm)"),
+          ("composition", 320, 16, "whole sphere traversal, r = 4e7 ground"),
+          ("final_scene_small", 240, 16, "slab node loop of a general scene in LDS (node_loop_slab16)"),
+          ("final_scene", 240, 9, "four-wide binary16 node loop (node_loop_wide16)")]
+
+
+@pytest.mark.parametrize("name,width,spp,what", SCENES)
+def test_frames_of_the_asm_and_the_compiled_traversals_are_identical(ctx, name, width, spp, what):
+    tex = earth_texels() if name.startswith("final_scene") else None
+    g = ra.Scene(name, width, ASPECT, "uniform", spp, 50, texels=tex)
+    dev = g.upload(ctx)
+    cam = g.camera_copy()
+    try:
+        ctx.set_option("fused_stats", 0)
+        production = dev.render_sums(cam, seed=21)
+        rays = ctx.stats()["rays"]
+        ctx.set_option("fused_stats", 1)  # instrumented build: the compiled C++ traversal with counters
+        compiled = dev.render_sums(cam, seed=21)
+        st = ctx.stats()
+    finally:
+        ctx.set_option("fused_stats", 0)
+    assert production.max() > 0 and np.isfinite(production).all()
+    assert st["rays"] == rays, what
+    assert np.array_equal(production, compiled), (what, float(np.mean(production != compiled)))
+    dev.close()
+
+
+def primary_rays(g, n_side=96, time=0.37):
+    """A grid of rays through the camera's viewport (deterministic), plus their mirror images from behind the scene."""
+    cam = g.camera_copy()
+    ys, xs = np.meshgrid(np.linspace(0, cam.height - 1, n_side), np.linspace(0, cam.width - 1, n_side), indexing="ij")
+    o = np.tile(np.array(cam.center), (n_side * n_side, 1))
+    p = (np.array(cam.pixel00)[None, :] + xs.reshape(-1, 1) * np.array(cam.du)[None, :] +
+         ys.reshape(-1, 1) * np.array(cam.dv)[None, :])
+    d = p - o
+    rays = np.zeros(2 * n_side * n_side, dtype=ra.RAY_DTYPE)
+    rays["o"][: len(o)] = o
+    rays["d"][: len(o)] = d
+    rays["o"][len(o):] = o + 3.0 * d  # from the far side, looking back
+    rays["d"][len(o):] = -d
+    rays["time"] = time
+    return rays
+
+
+@pytest.mark.parametrize("name,width,form", [("book_cover", 400, 3), ("final_scene_small", 240, 3),
+                                             ("final_scene", 240, 4), ("cornell_smoke", 200, 3)])
+def test_probe_hits_of_the_asm_and_the_counting_traversals_are_identical(ctx, name, width, form):
+    tex = earth_texels() if name.startswith("final_scene") else None
+    g = ra.Scene(name, width, ASPECT, "uniform", 4, 50, texels=tex)
+    dev = g.upload(ctx)
+    rays = primary_rays(g)
+    try:
+        ctx.set_option("probe_tree", form)
+        ctx.set_option("probe_count", 0)
+        before = ctx.stats()["probe_node_visits"]
+        production = dev.intersect(rays)
+        assert ctx.stats()["probe_node_visits"] == before  # the render kernels' instantiation does not count
+        ctx.set_option("probe_count", 1)
+        counted = dev.intersect(rays)
+        if name != "cornell_smoke":  # (eight primitives: no tree at all)
+            assert ctx.stats()["probe_node_visits"] > before
+    finally:
+        ctx.set_option("probe_count", 0)
+        ctx.set_option("probe_tree", 0)
+    media = name in ("final_scene", "final_scene_small", "cornell_smoke")
+    hit = production["object_id"] >= 0
+    assert hit.sum() > 1000
+    if not media:
+        for f in production.dtype.names:
+            assert np.array_equal(production[f], counted[f]), f
+    else:
+        # constant media draw from a per-ray stream inside the traversal: both forms test the same primitives in the
+        # same order, so even those hits agree
+        for f in ("object_id", "t", "p", "n", "front_face"):
+            assert np.array_equal(production[f], counted[f]), f
+    dev.close()
