@@ -908,7 +908,9 @@ __device__ __forceinline__ void node_loop_wide16(const Acc& acc, TravState& ts, 
   const uint32_t cache_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lds_addr(acc.cache));
   const uint32_t n_cached = (uint32_t)__builtin_amdgcn_readfirstlane(acc.n_cached);
   need = (uint32_t)__builtin_amdgcn_readfirstlane((int)need);
-  const SlabRay& r = ts.s;
+  // (by value: the asm's inputs are twelve scalars, not a view of the aggregate)
+  const float c_ix = ts.s.mx.x, c_ixw = ts.s.mx.y, c_iy = ts.s.my.x, c_iyw = ts.s.my.y, c_iz = ts.s.mz.x, c_izw = ts.s.mz.y;
+  const float c_nx = ts.s.ax.x, c_ox = ts.s.ax.y, c_ny = ts.s.ay.x, c_oy = ts.s.ay.y, c_nz = ts.s.az.x, c_oz = ts.s.az.y;
 // one child: entry distance -> TN, exit distance -> v68, hit mask (entry <= exit) -> HIT; v69 is scratch
 #define RT_WIDE_CHILD(TN, HIT, EX, EY, EZ, FX, FY, FZ, SEL)                                                      \
   "v_fma_mix_f32 " TN ", " EX ", %[ix], -%[nx] " SEL "\n"                                                      \
@@ -1016,8 +1018,8 @@ __device__ __forceinline__ void node_loop_wide16(const Acc& acc, TravState& ts, 
       "s_waitcnt lgkmcnt(0)\n"
       : [cur] "+v"(ts.cur), [sp] "+v"(ts.sp), [top] "+v"(ts.top)
       : [need] "s"(need), [stride] "s"(stride_bytes), [ncached] "s"(n_cached), [cbase] "s"(cache_base), [nodes] "s"(acc.nodes4h),
-        [tmax] "v"(ts.tmax_w), [ix] "v"(r.mx.x), [ixw] "v"(r.mx.y), [iy] "v"(r.my.x), [iyw] "v"(r.my.y), [iz] "v"(r.mz.x),
-        [izw] "v"(r.mz.y), [nx] "v"(r.ax.x), [ox] "v"(r.ax.y), [ny] "v"(r.ay.x), [oy] "v"(r.ay.y), [nz] "v"(r.az.x), [oz] "v"(r.az.y)
+        [tmax] "v"(ts.tmax_w), [ix] "v"(c_ix), [ixw] "v"(c_ixw), [iy] "v"(c_iy), [iyw] "v"(c_iyw), [iz] "v"(c_iz),
+        [izw] "v"(c_izw), [nx] "v"(c_nx), [ox] "v"(c_ox), [ny] "v"(c_ny), [oy] "v"(c_oy), [nz] "v"(c_nz), [oz] "v"(c_oz)
       : "vcc", "scc", "memory", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
         "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89",
         "s90", "s91", "s92", "s93", "s94", "s95", "s98");
