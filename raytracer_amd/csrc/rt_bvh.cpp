@@ -156,9 +156,152 @@ struct Builder {
   }
 };
 
+// ---- Reinsertion pass (after Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding volume
+// hierarchies", CGF 2013).  The top-down binned build fixes every split before it knows what lies below it; this pass
+// takes subtrees out, largest boxes first, and puts each back where it enlarges the tree's boxes least — found by
+// branch and bound over the induced cost (the growth of the ancestors' areas), the old position among the candidates,
+// so the summed area of the inner nodes (SAH with one primitive per leaf) never grows.  The tree's depth is held to the
+// built tree's: the traversal stacks in LDS are sized by it.  Closest hits do not depend on the topology.
+struct Optimiser {
+  struct TN {
+    Box box;
+    int parent, child[2];
+    int32_t prim;  // >= 0: leaf
+  };
+  const std::vector<Box>& boxes;
+  std::vector<TN> t;
+  int root = -1;
+
+  explicit Optimiser(const std::vector<Box>& b) : boxes(b) {}
+  static double area(const Box& b) { return Builder::area(b); }
+  static Box merged(const Box& a, const Box& b) { Box m = a; Builder::grow(m, b); return m; }
+
+  int import(const std::vector<FlatNode>& nodes, int32_t ref, int parent) {
+    const int me = (int)t.size();
+    t.emplace_back();
+    t[(size_t)me].parent = parent;
+    if (ref < 0) {
+      t[(size_t)me].prim = ~ref;
+      t[(size_t)me].child[0] = t[(size_t)me].child[1] = -1;
+      t[(size_t)me].box = boxes[(size_t)~ref];
+      return me;
+    }
+    const int l = import(nodes, nodes[(size_t)ref].left, me), r = import(nodes, nodes[(size_t)ref].right, me);
+    TN& n = t[(size_t)me];
+    n.prim = -1; n.child[0] = l; n.child[1] = r;
+    n.box = merged(t[(size_t)l].box, t[(size_t)r].box);
+    return me;
+  }
+  void refit_up(int n) {
+    for (; n >= 0; n = t[(size_t)n].parent) t[(size_t)n].box = merged(t[(size_t)t[(size_t)n].child[0]].box, t[(size_t)t[(size_t)n].child[1]].box);
+  }
+  int depth_of(int n) const { int d = 0; for (n = t[(size_t)n].parent; n >= 0; n = t[(size_t)n].parent) d++; return d; }
+  int height_of(int n) const {
+    if (t[(size_t)n].prim >= 0) return 0;
+    return 1 + std::max(height_of(t[(size_t)n].child[0]), height_of(t[(size_t)n].child[1]));
+  }
+  double inner_area() const {
+    double s = 0;
+    for (const TN& n : t) if (n.prim < 0 && n.parent >= -1) s += area(n.box);
+    return s;
+  }
+  // takes n (and its parent p) out, returns p for reuse; n's sibling takes p's place
+  int detach(int n) {
+    const int p = t[(size_t)n].parent, g = t[(size_t)p].parent;
+    const int s = t[(size_t)p].child[0] == n ? t[(size_t)p].child[1] : t[(size_t)p].child[0];
+    t[(size_t)s].parent = g;
+    if (g < 0) root = s;
+    else { t[(size_t)g].child[t[(size_t)g].child[0] == p ? 0 : 1] = s; refit_up(g); }
+    return p;
+  }
+  // p becomes the parent of x and n, in x's place
+  void attach(int n, int p, int x) {
+    const int g = t[(size_t)x].parent;
+    t[(size_t)p].parent = g;
+    t[(size_t)p].child[0] = x; t[(size_t)p].child[1] = n;
+    t[(size_t)x].parent = p; t[(size_t)n].parent = p;
+    if (g < 0) root = p;
+    else t[(size_t)g].child[t[(size_t)g].child[0] == x ? 0 : 1] = p;
+    refit_up(p);
+  }
+  // where n's subtree (height h) costs least, among positions that keep the tree within max_depth levels
+  int best_position(int n, int h, int max_levels) const {
+    struct Item { double induced; int node, depth; };
+    auto later = [](const Item& a, const Item& b) { return a.induced > b.induced; };
+    std::vector<Item> heap;
+    heap.push_back({0.0, root, 0});
+    const Box& nb = t[(size_t)n].box;
+    const double na = area(nb);
+    double best_cost = INF;
+    int best = -1;
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), later);
+      const Item it = heap.back();
+      heap.pop_back();
+      if (it.induced + na >= best_cost) break;
+      const TN& x = t[(size_t)it.node];
+      const double direct = area(merged(x.box, nb));
+      // the new parent sits at x's depth; below it: x's subtree and n's, each one level deeper
+      if (it.induced + direct < best_cost && it.depth + 1 + h <= max_levels &&
+          (x.prim >= 0 || it.depth + 1 + height_of(it.node) <= max_levels)) {
+        best_cost = it.induced + direct;
+        best = it.node;
+      }
+      if (x.prim < 0) {
+        const double below = it.induced + direct - area(x.box);
+        if (below + na < best_cost)
+          for (int k = 0; k < 2; k++) {
+            heap.push_back({below, x.child[k], it.depth + 1});
+            std::push_heap(heap.begin(), heap.end(), later);
+          }
+      }
+    }
+    return best;
+  }
+  void run(int passes, int max_levels) {
+    std::vector<int> order;
+    for (int pass = 0; pass < passes; pass++) {
+      order.clear();
+      for (int i = 0; i < (int)t.size(); i++)
+        if (i != root && t[(size_t)i].parent != root) order.push_back(i);
+      std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const double aa = area(t[(size_t)a].box), ab = area(t[(size_t)b].box);
+        return aa != ab ? aa > ab : a < b;
+      });
+      const double before = inner_area();
+      for (int n : order) {
+        if (n == root || t[(size_t)n].parent == root || t[(size_t)n].parent < 0) continue;
+        const int h = height_of(n);
+        const int old_sibling = t[(size_t)t[(size_t)n].parent].child[0] == n ? t[(size_t)t[(size_t)n].parent].child[1]
+                                                                              : t[(size_t)t[(size_t)n].parent].child[0];
+        const int p = detach(n);
+        int x = best_position(n, h, max_levels);
+        if (x < 0) x = old_sibling;  // (depth limit left no candidate: back where it was)
+        attach(n, p, x);
+      }
+      if (!(inner_area() < before * (1.0 - 1e-4))) break;
+    }
+  }
+  int depth() const { return height_of(root); }
+  // back to the flat form, numbered in the order the builder numbers (pre-order, left subtree first)
+  int32_t flatten(int n, std::vector<FlatNode>& out) const {
+    const TN& tn = t[(size_t)n];
+    if (tn.prim >= 0) return ~tn.prim;
+    const int32_t me = (int32_t)out.size();
+    out.emplace_back();
+    const int32_t l = flatten(tn.child[0], out), r = flatten(tn.child[1], out);
+    FlatNode& nd = out[(size_t)me];
+    Builder::store(t[(size_t)tn.child[0]].box, nd.l_lo, nd.l_hi);
+    Builder::store(t[(size_t)tn.child[1]].box, nd.r_lo, nd.r_hi);
+    nd.left = l; nd.right = r;
+    nd.pad[0] = nd.pad[1] = 0;
+    return me;
+  }
+};
+
 }  // namespace
 
-BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth) {
+BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth, int optimise_passes) {
   BuildResult res;
   if (boxes.empty()) return res;
   Builder b(boxes, max_depth);
@@ -167,9 +310,21 @@ BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth) {
   res.root = b.build(0, boxes.size(), 0, root_box);
   res.nodes = std::move(b.nodes);
   res.depth = b.depth_seen;
+  // (the pass is quadratic in the worst case through height_of: scenes of up to 8 Ki primitives)
+  if (optimise_passes > 0 && res.root >= 0 && boxes.size() >= 8 && boxes.size() <= 8192) {
+    Optimiser o(boxes);
+    o.t.reserve(2 * boxes.size());
+    o.root = o.import(res.nodes, res.root, -1);
+    o.run(optimise_passes, res.depth);
+    if (o.depth() <= res.depth) {
+      std::vector<FlatNode> flat;
+      flat.reserve(res.nodes.size());
+      const int32_t r = o.flatten(o.root, flat);
+      if (r >= 0 && flat.size() == res.nodes.size()) { res.nodes.swap(flat); res.root = r; res.depth = o.depth(); }
+    }
+  }
   return res;
 }
-
 
 namespace {
 struct Cand {

@@ -27,7 +27,8 @@ struct BuildResult {
 };
 
 // boxes[i] = f64 bounds of primitive i.  max_depth bounds the tree depth (traversal stack size).
-BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth);
+// optimise_passes > 0: that many rounds of the reinsertion pass afterwards (rt_bvh.cpp); the depth never grows.
+BuildResult build_bvh(const std::vector<Box>& boxes, int max_depth, int optimise_passes = 0);
 
 
 // Four-wide form of the same tree for the instances that traverse out of HBM/L2 (one 128-byte line per step, about

@@ -584,22 +584,31 @@ RT_AABOX_INLINE bool aabox_hit(const Prim& P, d3 blo, d3 bhi, d3 o, d3 d, const 
   const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   const double lo3[3] = {blo.x, blo.y, blo.z}, hi3[3] = {bhi.x, bhi.y, bhi.z};
   const float r32[3] = {s.mx.x, s.my.x, s.mz.x};  // f32 reciprocals of the direction (make_slab)
-  double te = -__builtin_inf(), tx = __builtin_inf();
-  int fe = 0, fx = 0;
+  // per axis: distances to the two planes; the nearer is the entry (min), the farther the exit (max) — the same two
+  // products the sign-selected form computes, without its eight selects; an axis the ray is parallel to takes no part
+  double tn[3], tf[3];
+  bool neg[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const double lo = lo3[a], hi = hi3[a];
+    neg[a] = dd[a] < 0.;
     if (__builtin_fabs(dd[a]) < 1e-8) {
       if (oo[a] < lo || oo[a] > hi) return false;
+      tn[a] = -__builtin_inf(); tf[a] = __builtin_inf();
     } else {
       double r = (double)r32[a];
       r = __builtin_fma(__builtin_fma(-dd[a], r, 1.0), r, r);  // one Newton step: ~1e-14 relative
-      const bool neg = dd[a] < 0.;
-      const double tn = ((neg ? hi : lo) - oo[a]) * r, tf = ((neg ? lo : hi) - oo[a]) * r;
-      if (tn > te) { te = tn; fe = 2 * a + (neg ? 1 : 0); }
-      if (tf < tx) { tx = tf; fx = 2 * a + (neg ? 0 : 1); }
+      const double ta = (lo - oo[a]) * r, tb = (hi - oo[a]) * r;
+      tn[a] = __builtin_fmin(ta, tb); tf[a] = __builtin_fmax(ta, tb);
     }
   }
+  // entry = latest near plane, exit = earliest far plane; ties keep the earlier axis (as the running comparison did)
+  int fe = neg[0] ? 1 : 0, fx = neg[0] ? 0 : 1;
+  double te = tn[0], tx = tf[0];
+  if (tn[1] > te) { te = tn[1]; fe = 2 + (neg[1] ? 1 : 0); }
+  if (tf[1] < tx) { tx = tf[1]; fx = 2 + (neg[1] ? 0 : 1); }
+  if (tn[2] > te) { te = tn[2]; fe = 4 + (neg[2] ? 1 : 0); }
+  if (tf[2] < tx) { tx = tf[2]; fx = 4 + (neg[2] ? 0 : 1); }
   if (!(te <= tx) || te == -__builtin_inf()) return false;  // (te = -inf: every axis parallel — a degenerate direction)
   // exact t of the chosen face: the entry face unless it is not beyond tmin, then the exit face
   int f = fe;

@@ -334,6 +334,7 @@ static_assert(sizeof(WgSched) % 16 == 0, "scheduler block keeps the LDS regions 
 #ifndef RT_HEAVY_BLOCK
 #define RT_HEAVY_BLOCK 1024
 #endif
+#define RT_STATS_HEAVY_BLOCK 768  // the instrumented build of the same instance (see render_fused)
 enum { KIND_GENERIC = 0, KIND_SPHERES_GLOBAL = 1, KIND_SPHERES_LDS = 2, KIND_GENERIC_LDS = 3, KIND_GENERIC_WIDE = 4, KIND_SPHERES_WIDE = 5,
        KIND_GENERIC_WIDE_HALF = 6, KIND_SPHERES_WIDE_HALF = 7 };
 constexpr bool kind_caches_top(int k) { return k == KIND_GENERIC_WIDE_HALF || k == KIND_SPHERES_WIDE_HALF; }
@@ -1187,6 +1188,7 @@ struct rt_ctx {
   const unsigned long long* last_ray_total = nullptr;  // ray counter of the last render (rt_get_stats)
   const uint32_t* last_watchdog = nullptr;             // watchdog flag of the last fused render
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
+  int bvh_optimise = 3;  // rounds of the reinsertion pass after the binned-SAH build (read at scene upload; 0 = the built tree)
   int probe_count = 0;  // probe_tree 3 / 4: count node visits / primitive tests (instrumented traversal) instead of running the render kernels' own
   unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
@@ -1439,6 +1441,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "probe_tree") {
     if (value < 0 || value > 4) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be in 0..4");
     ctx->probe_tree = (int)value;
+  } else if (k == "bvh_optimise") {
+    if (value < 0 || value > 16) return fail(ctx, RT_E_INVALID_ARG, "bvh_optimise must be in 0..16");
+    ctx->bvh_optimise = (int)value;
   } else if (k == "probe_count") {
     ctx->probe_count = value ? 1 : 0;
   } else if (k == "fused_tail4" || k == "fused_tail2") {
@@ -1738,7 +1743,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
       tree_boxes.push_back(boxes[(size_t)i]);
     }
   // (a tiny scene keeps its tree in memory — probe forms and sizes are unchanged — but no render or probe walks it)
-  rtb::BuildResult bvh = rtb::build_bvh(tree_boxes, RT_STACK_DEPTH);
+  rtb::BuildResult bvh = rtb::build_bvh(tree_boxes, RT_STACK_DEPTH, ctx->bvh_optimise);
   {  // leaf references back to positions in the primitive tables
     auto fix = [&in_tree](int32_t& ref) { if (ref < 0 && ref != rtb::EMPTY_CHILD) ref = ~in_tree[(size_t)~ref]; };
     for (rtb::FlatNode& nd : bvh.nodes) { fix(nd.left); fix(nd.right); }
@@ -2466,7 +2471,10 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     // scene's coordinates fit binary16 and its references the 16-bit stack.  768 threads (3 waves/SIMD, 168 VGPRs)
     // for the instances with the noise code, 1024 otherwise.
     const bool heavy = !(scene->spheres_only && lean);  // instances compiled with RT_F_TEX_NOISE
-    const uint32_t cblock = heavy ? (uint32_t)RT_HEAVY_BLOCK : 1024u;
+    // (the INSTRUMENTED general instance keeps 768 threads / 168 VGPRs: with its counters on top, the 128-VGPR form spills
+    // 165 VGPRs and 98 SGPRs, and its counts — never the frame — came back different from run to run)
+    const bool stats_general = ctx->fused_stats && !scene->spheres_only;
+    const uint32_t cblock = heavy ? (stats_general ? (uint32_t)RT_STATS_HEAVY_BLOCK : (uint32_t)RT_HEAVY_BLOCK) : 1024u;
     // (slots before cache: 2 per wave + 8, if the stacks leave that much)
     const size_t cbase = RT_SCHED_BYTES + (size_t)sd * cblock * 2;
     const uint32_t cslots = cbase + 16 * 64 < 160 * 1024 ? fused_slots(ctx, 2 * (cblock / 64) + 8, 160 * 1024 - cbase - 16 * 64) : cblock / 64;
@@ -2479,8 +2487,8 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
       if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 1024, int16_t>(ctx, scene, dc, fp, csmem, st);
       else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);
       else if (ctx->fused_stats) {
-        if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t, true, true>(ctx, scene, dc, fp, csmem, st);
-        else rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t, true, false>(ctx, scene, dc, fp, csmem, st);
+        if (use_resume(ctx, scene)) rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_STATS_HEAVY_BLOCK, int16_t, true, true>(ctx, scene, dc, fp, csmem, st);
+        else rc = launch_fused<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_STATS_HEAVY_BLOCK, int16_t, true, false>(ctx, scene, dc, fp, csmem, st);
       } else if (scene->features & RT_F_BOX) rc = launch_variant<RT_F_ALL, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);
       else rc = launch_variant<RT_F_ALL_NOBOX, KIND_GENERIC_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);
     } else if (wide) { RT_GLOBAL_DISPATCH(KIND_SPHERES_WIDE, KIND_GENERIC_WIDE) }

@@ -108,3 +108,30 @@ def test_probe_hits_of_the_asm_and_the_counting_traversals_are_identical(ctx, na
         for f in ("object_id", "t", "p", "n", "front_face"):
             assert np.array_equal(production[f], counted[f]), f
     dev.close()
+
+
+@pytest.mark.parametrize("name,width,spp", [("final_scene", 480, 16), ("book_cover", 320, 16)])
+def test_production_frames_are_repeatable_inside_one_context(ctx, name, width, spp):
+    """The final-scene instance runs at 128 VGPRs with register spills around its asm traversal; its
+    INSTRUMENTED sibling at that budget returned counters that changed from its second frame on (stale scratch), and
+    therefore runs at 768 threads.  The production kernel must give the same bits and the same ray count every time —
+    also after other kernels, an instrumented frame among them, have used the scratch memory."""
+    tex = earth_texels() if name.startswith("final_scene") else None
+    g = ra.Scene(name, width, ASPECT, "uniform", spp, 50, texels=tex)
+    dev = g.upload(ctx)
+    cam = g.camera_copy()
+    ref = dev.render_sums(cam, seed=3)
+    rays = ctx.stats()["rays"]
+    for i in range(6):
+        if i == 3:
+            ctx.set_option("fused_stats", 1)
+            try:
+                counted = dev.render_sums(cam, seed=3)
+                assert ctx.stats()["rays"] == rays
+            finally:
+                ctx.set_option("fused_stats", 0)
+            assert np.array_equal(counted, ref)
+        again = dev.render_sums(cam, seed=3)
+        assert ctx.stats()["rays"] == rays, i
+        assert np.array_equal(again, ref), i
+    dev.close()
