@@ -261,7 +261,7 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * in flight per pass), "profile" (wavefront: 1 = per-stage hipEvent timing, serialises stages), "fused_ku" (samples
  * per work unit, 0 = auto), "fused_lds" (1 = keep the scene in LDS when it fits), "fused_resume" (traversal
  * schedule: 0 bounce-synchronous, 1 resumable, 2 = by scene size, default) with "fused_kb" / "fused_kn" /
- * "fused_kr" (hand-back, node-loop exit and regeneration thresholds, 1..64), "fused_wide" / "fused_half" (scenes
+ * "fused_kr" (hand-back, node-loop exit and regeneration thresholds, 1..64; defaults 16 / 8 / by residency: 16 for scenes kept in LDS, 12 for scenes read through the caches), "fused_wide" / "fused_half" (scenes
  * that do not fit LDS: 1 = four-wide tree / its binary16 form with the top levels cached in LDS, defaults; 0 = the
  * binary tree / f32 planes, kept as cross-checks), "fused_tail4" / "fused_tail2" (height, in per mille of the frame's rows, of the bands of 4x4 / 2x2 tiles at the
  * end of the tile list that keep the frame's tail short; 50 / 30; never changes the frame), "fused_slots" (tiles a workgroup keeps in flight,

@@ -1162,7 +1162,7 @@ struct rt_ctx {
   int fused_ku = 0;          // samples per work unit (0 = auto)
   int fused_lds = 1;         // keep the scene in LDS when it fits
   int fused_stats = 0;       // diagnostic: instrumented fused kernel (lean LDS variant only)
-  int fused_kr = 16;
+  int fused_kr = 0;  // regeneration threshold of the resumable schedule; 0 = by residency: 16 for scenes in LDS, 12 read through the caches
   std::map<std::pair<const void*, size_t>, int> fused_occupancy;  // workgroups per CU of (kernel instance, LDS bytes)
   std::map<const void*, size_t> fused_lds_opt_in;                 // dynamic LDS ceiling set per kernel instance
   int fused_partner_min = 32;  // partner workgroups only for frames of at least this many Mi samples (C2 split 1 / 2 / 4 / 8 ways:
@@ -1944,7 +1944,7 @@ static int launch_probe_kind(rt_ctx* ctx, const rt_scene* scene, const rt_ray* d
   }
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((m + BLOCK - 1) / BLOCK, (uint32_t)ctx->n_cu));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), smem, ctx->stream, scene->view, scene->features, d_rays, m, d_hits, n_cached,
-                     (uint32_t)ctx->fused_kb, (uint32_t)ctx->fused_kn, (uint32_t)ctx->fused_kr, ctx->d_trav);
+                     (uint32_t)ctx->fused_kb, (uint32_t)ctx->fused_kn, (uint32_t)(ctx->fused_kr ? ctx->fused_kr : kind_in_lds(KIND) ? 16 : 12), ctx->d_trav);
   HIP_TRY(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -2388,6 +2388,9 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
   // keeps neighbouring rays on neighbouring nodes and texels, and the reordered frame measured 1 % slower)
   const bool in_lds = ctx->fused_lds && small_ids &&
                       (scene->spheres_only ? lds_1024 <= 160 * 1024 : lds_generic_1024 <= 160 * 1024);
+  // (final scene, kr x kb swept after the traversal went into asm: 12 / 16 -> 38.1 ms, 16 / 16 -> 38.4, 8 / 16 -> 38.2;
+  // LDS-resident C2 is flat from 16 to 24 and loses below)
+  if (use_resume(ctx, scene) && ctx->fused_kr == 0) fp.kr = in_lds ? 16u : 12u;
   if (ctx->fused_feedback && in_lds && ctx->fs == &ctx->own) {
     if (fp.tiles_per_frame > ctx->tile_cap) {
       HIP_TRY(ctx, hipStreamSynchronize(st));
