@@ -1188,6 +1188,7 @@ struct rt_ctx {
   const unsigned long long* last_ray_total = nullptr;  // ray counter of the last render (rt_get_stats)
   const uint32_t* last_watchdog = nullptr;             // watchdog flag of the last fused render
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
+  int dbg_max_cached = 0;  // test hook: cap of the four-wide nodes kept in LDS (0 = as many as fit), so that small scenes reach the memory path
   int bvh_optimise = 3;  // rounds of the reinsertion pass after the binned-SAH build (read at scene upload; 0 = the built tree)
   int probe_count = 0;  // probe_tree 3 / 4: count node visits / primitive tests (instrumented traversal) instead of running the render kernels' own
   unsigned long long probe_rays = 0;
@@ -1441,6 +1442,9 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "probe_tree") {
     if (value < 0 || value > 4) return fail(ctx, RT_E_INVALID_ARG, "probe_tree must be in 0..4");
     ctx->probe_tree = (int)value;
+  } else if (k == "dbg_max_cached") {
+    if (value < 0 || value > 65535) return fail(ctx, RT_E_INVALID_ARG, "dbg_max_cached out of range");
+    ctx->dbg_max_cached = (int)value;
   } else if (k == "bvh_optimise") {
     if (value < 0 || value > 16) return fail(ctx, RT_E_INVALID_ARG, "bvh_optimise must be in 0..16");
     ctx->bvh_optimise = (int)value;
@@ -2486,6 +2490,7 @@ static int render_fused(rt_ctx* ctx, const rt_scene* scene, const rt_camera* cam
     if (wide && ctx->fused_half && scene->half_ok && ids16 && cfixed + 16 * 64 <= 160 * 1024) {
       fp.n_slots = cslots;
       fp.n_cached = (uint32_t)std::min<size_t>((size_t)scene->view.n_nodes4, (160 * 1024 - cfixed) / 64);
+      if (ctx->dbg_max_cached > 0) fp.n_cached = std::min<uint32_t>(fp.n_cached, (uint32_t)ctx->dbg_max_cached);  // test hook
       const size_t csmem = cfixed + (size_t)fp.n_cached * 64;
       if (scene->spheres_only && lean) rc = launch_variant<RT_F_TEX_CHECKER, KIND_SPHERES_WIDE_HALF, 1024, int16_t>(ctx, scene, dc, fp, csmem, st);
       else if (scene->spheres_only) rc = launch_variant<RT_F_TEX_ANY, KIND_SPHERES_WIDE_HALF, RT_HEAVY_BLOCK, int16_t>(ctx, scene, dc, fp, csmem, st);

@@ -135,3 +135,20 @@ def test_production_frames_are_repeatable_inside_one_context(ctx, name, width, s
         assert ctx.stats()["rays"] == rays, i
         assert np.array_equal(again, ref), i
     dev.close()
+
+
+def test_partly_cached_four_wide_tree_gives_the_same_frame(ctx):
+    """node_loop_wide16 fetches a node from the LDS copy of the top of the tree or, past it, from memory (two exec-masked
+    paths in one step).  The final scene's tree fits LDS whole; capped to 48 and to 300 nodes the memory path runs for
+    most / some of the steps — the frame must not change."""
+    g = ra.Scene("final_scene", 240, ASPECT, "uniform", 9, 50, texels=earth_texels())
+    dev = g.upload(ctx)
+    cam = g.camera_copy()
+    ref = dev.render_sums(cam, seed=8)
+    try:
+        for cap in (48, 300, 1):
+            ctx.set_option("dbg_max_cached", cap)
+            assert np.array_equal(dev.render_sums(cam, seed=8), ref), cap
+    finally:
+        ctx.set_option("dbg_max_cached", 0)
+    dev.close()
