@@ -1316,8 +1316,11 @@ template <class Acc>
 __device__ __forceinline__ void global_prims_test(const Acc& acc, const GlobalPrims& gp, TravState& ts, uint32_t features, d3 o,
                                                   d3 d, double time, double tmin, PathRng& rng) {
   // (a loop, not eight copies of the test: the list's length is a run-time value and the code stays in the instruction cache)
+  // (the list is read through the constant address space: a scalar load the compiler may issue early, the index and
+  // everything derived from it in SGPRs — a plain load became a vector load the wave waited on in every round)
+  const __attribute__((address_space(4))) int32_t* list = (const __attribute__((address_space(4))) int32_t*)(uintptr_t)gp.list;
 #pragma unroll 1
-  for (int g = 0; g < gp.n; g++) prim_test(acc, ts, gp.list[g], features, o, d, time, tmin, rng);
+  for (int g = 0; g < gp.n; g++) prim_test(acc, ts, list[g], features, o, d, time, tmin, rng);
 }
 
 template <class Acc>
