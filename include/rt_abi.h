@@ -276,7 +276,7 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* out);
  * 1 four-wide f32; 2 four-wide binary16; 3 and 4 the PRODUCTION forms under the render loop's own schedule — resumable
  * traversals, 16-bit sentinel stack — 3 = the scene copied into LDS as the render kernels keep it (slab nodes), 4 = the
  * four-wide binary16 tree with its top cached in LDS (partner workgroups / HBM-resident instances); with 3 and 4 rt_hit.n
- * and rt_hit.front_face are the render path's own f32 shading normal and front test; "dbg_max_cached" (test hook: at most that many four-wide nodes are kept in LDS, the rest is read from memory; 0 = as many as fit; frames unchanged), "bvh_optimise" (read at scene upload: rounds of the reinsertion pass over the binned-SAH tree, 0..16, default 3; the tree's depth never grows and hits do not depend on it); "probe_count" = 1 makes 3 and 4 run the
+ * and rt_hit.front_face are the render path's own f32 shading normal and front test; "dbg_max_cached" (test hook: at most that many four-wide nodes are kept in LDS, the rest is read from memory; 0 = as many as fit; frames unchanged), "uv_tables" (read at scene upload, default 1: image textures get a table of their texel boundaries, against which sphere hits check an f32 guess of the texel instead of evaluating the f64 acos / atan2 of get_sphere_uv; a failed check evaluates the formulas; 0 = the formulas always; frames identical), "bvh_optimise" (read at scene upload: rounds of the reinsertion pass over the binned-SAH tree, 0..16, default 3; the tree's depth never grows and hits do not depend on it); "probe_count" = 1 makes 3 and 4 run the
  * instrumented C++ traversal that fills rt_stats.probe_node_visits / probe_prim_tests, 0 = default: the render kernels' own
  * instantiation, for sphere scenes in LDS the hand-scheduled asm traversal), "fused_stats" (1 = instrumented kernel, fills rt_stats.dbg).  Thresholds, unit size and tile order never change the frame, and
  * the kernel variants give bit-identical frames (FP contraction is fixed per source expression in all device code).  Unknown keys and out-of-range values

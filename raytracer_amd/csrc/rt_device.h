@@ -66,7 +66,8 @@ struct Texture {  // 64 B
   uint32_t texel_off;  // in texels (RGBA8 words)
   float rgb[3];        // SOLID colour, or the inlined `odd` child of a CHECKER
   float rgb2[3];       // inlined `even` child of a CHECKER
-  uint32_t pad[2];
+  uint32_t uvtab_off;  // IMAGE: 32-bit words from Scene::texels to the table of sphere_texel_checked; 0 = none
+  uint32_t pad;
   double inv_scale;
 };
 
@@ -1432,10 +1433,15 @@ struct HitRec {
 #pragma clang fp contract(off)
 __device__ __forceinline__ void sphere_uv(d3 on, double& u, double& v) {  // geometry.rs:30-34
   const double PI = 3.14159265358979323846;
+#ifdef RT_EXP_F32_UV
+  double theta = (double)acosf((float)-on.y);
+  double phi = (double)atan2f((float)-on.z, (float)on.x) + PI;
+#else
   double theta = acos(-on.y);
   double phi = atan2(-on.z, on.x) + PI;
-  u = phi / (2. * PI);
-  v = theta / PI;
+#endif
+  u = div_noscale(phi, 2. * PI);  // (operands in the normal range: the scaling-free division rounds like `/`)
+  v = div_noscale(theta, PI);
 }
 template <class Acc>
 __device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 d, double time, double t, bool want_uv) {
@@ -1445,7 +1451,7 @@ __device__ __forceinline__ HitRec make_hit(const Acc& acc, int32_t pi, d3 o, d3 
   if (Acc::kSpheresOnly || acc.type(pi) <= 1u) {
     PrimGeom g = acc.sphere(pi);
     d3 c = sphere_center(g, time);
-    h.outward = {(h.p.x - c.x) / g.r, (h.p.y - c.y) / g.r, (h.p.z - c.z) / g.r};
+    h.outward = {div_noscale(h.p.x - c.x, g.r), div_noscale(h.p.y - c.y, g.r), div_noscale(h.p.z - c.z, g.r)};
     if (want_uv) { sphere_uv(h.outward, h.u, h.v); h.uv_valid = true; }
   } else if (acc.type(pi) >= 3u) {  // medium scatter event: arbitrary normal, front face (book convention)
     h.outward = {1., 0., 0.};
@@ -1527,6 +1533,50 @@ __device__ __forceinline__ double rem_euclid1(double a) {  // f64::rem_euclid(1.
   double r = a - trunc(a);  // == fmod(a, 1.0) exactly
   return r < 0.0 ? r + 1.0 : r;
 }
+// atan2(y, x) / 2 pi in f32: octant reduction, t * P(t^2) with P fitted to atan(t) / (2 pi t) on [0, 1] (|error| 3e-8 of a
+// revolution in f32 evaluation); the sign of the result is y's sign bit, like atan2's.  x = y = 0 gives NaN.
+__device__ __forceinline__ float fast_atan2_rev(float y, float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float t = fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(ax, ay));
+  const float s = t * t;
+  float p = -0.0007689043413847685f;
+  p = fmaf(p, s, 0.003940164111554623f);
+  p = fmaf(p, s, -0.009584171697497368f);
+  p = fmaf(p, s, 0.01586444303393364f);
+  p = fmaf(p, s, -0.02234557457268238f);
+  p = fmaf(p, s, 0.03178910166025162f);
+  p = fmaf(p, s, -0.05305000767111778f);
+  p = fmaf(p, s, 0.15915493667125702f);
+  float r = p * t;
+  r = ay > ax ? 0.25f - r : r;
+  r = x < 0.f ? 0.5f - r : r;
+  return __builtin_copysignf(r, y);
+}
+// Texel (i, j) of a W x H image under a sphere's outward normal `on`, without the f64 acos and atan2 of get_sphere_uv
+// (geometry.rs:30-34) + ImageTexture::value (texture.rs:79-93), which are two thirds of what a path on the earth scene
+// costs.  The texel those formulas select is a function of WHERE `on` points: column i iff the longitude of (on.x, -on.z)
+// lies in [b_i, b_i+1), b_i = 2 pi i / W - pi; row j iff cos(pi (j+1) / H) < on.y <= cos(pi j / H).  So: GUESS (i, j) from
+// f32 arctangents, then CHECK the guess in f64 against the boundaries themselves — two cross products with the unit
+// vectors of b_i, b_i+1 and two comparisons with the cosines, all read from a table made at scene upload.  Returns false
+// when the check fails (the guess was a texel off: ~1e-4 of the hits; the normal is ON a boundary or the seam or a pole;
+// NaN) — the caller then evaluates the formulas, so every special case keeps the formulas' answer.  A passed check and
+// the formulas can disagree only where the formulas' own rounding decides, within a few ulps of a boundary (for a
+// 1024 x 512 image ~1e-13 of the hits) — the same class as the last-ulp differences between two libm's atan2.
+__device__ __forceinline__ bool sphere_texel_checked(d3 on, const double* __restrict__ tab, uint32_t W, uint32_t H, uint32_t& i,
+                                                     uint32_t& j) {
+  const float x = (float)on.x, y = (float)on.y, z = (float)on.z;
+  const float u = fast_atan2_rev(-z, x) + 0.5f;                                 // (phi + pi) / 2 pi
+  const float th = fast_atan2_rev(__builtin_amdgcn_sqrtf(fmaf(x, x, z * z)), -y);  // theta / 2 pi, theta = acos(-y) in [0, pi]
+  i = min((uint32_t)(u * (float)W), W - 1u);
+  j = min((uint32_t)((1.f - 2.f * th) * (float)H), H - 1u);
+  const double2* ut = reinterpret_cast<const double2*>(tab);
+  const double* vt = tab + 2 * ((size_t)W + 1);
+  const double2 b0 = ut[i], b1 = ut[i + 1];
+  const double c0 = vt[j], c1 = vt[j + 1];
+  const double px = on.x, py = -on.z;
+  const double lo = b0.x * py - b0.y * px, hi = b1.x * py - b1.y * px;  // > 0: counter-clockwise of the boundary
+  return lo >= 0. && hi < 0. && on.y <= c0 && on.y > c1;
+}
 template <uint32_t F, class Acc>
 __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t ti, int32_t pi, const HitRec& h0, d3 o,
                                         d3 d, double time, double t) {
@@ -1548,16 +1598,24 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
     }
     if ((F & RT_F_TEX_IMAGE) && kind == 2u) {  // texture.rs:79-93
       if (T.width == 0 || T.height == 0) return {0.f, 1.f, 1.f};
-      double u = h0.u, v = h0.v;
-      if (!h0.uv_valid) {
-        HitRec h = make_hit(acc, pi, o, d, time, t, true);
-        u = h.u; v = h.v;
+      uint32_t i = 0, j = 0;
+      bool have = false;
+      if (T.uvtab_off && !h0.uv_valid && (Acc::kSpheresOnly || acc.type(pi) <= 1u)) {
+        const HitRec h = make_hit(acc, pi, o, d, time, t, false);  // (the outward normal in f64, as the reference has it)
+        have = sphere_texel_checked(h.outward, reinterpret_cast<const double*>(sc.texels + T.uvtab_off), T.width, T.height, i, j);
       }
-      u = fmin(fmax(u, 0.0), 1.0);
-      v = 1.0 - fmin(fmax(v, 0.0), 1.0);
-      uint32_t i = (uint32_t)(u * (double)T.width), j = (uint32_t)(v * (double)T.height);
-      i = i > T.width - 1 ? T.width - 1 : i;  // deviation: clamp where the reference would panic
-      j = j > T.height - 1 ? T.height - 1 : j;
+      if (!have) {
+        double u = h0.u, v = h0.v;
+        if (!h0.uv_valid) {
+          HitRec h = make_hit(acc, pi, o, d, time, t, true);
+          u = h.u; v = h.v;
+        }
+        u = fmin(fmax(u, 0.0), 1.0);
+        v = 1.0 - fmin(fmax(v, 0.0), 1.0);
+        i = (uint32_t)(u * (double)T.width); j = (uint32_t)(v * (double)T.height);
+        i = i > T.width - 1 ? T.width - 1 : i;  // deviation: clamp where the reference would panic
+        j = j > T.height - 1 ? T.height - 1 : j;
+      }
       uint32_t px = sc.texels[T.texel_off + j * T.width + i];
       const float k = 1.0f / 255.0f;
       return {(float)(px & 0xffu) * k, (float)((px >> 8) & 0xffu) * k, (float)((px >> 16) & 0xffu) * k};

@@ -1190,6 +1190,7 @@ struct rt_ctx {
   unsigned long long* d_trav = nullptr;  // probe counters: node visits, prim tests
   int dbg_max_cached = 0;  // test hook: cap of the four-wide nodes kept in LDS (0 = as many as fit), so that small scenes reach the memory path
   int bvh_optimise = 3;  // rounds of the reinsertion pass after the binned-SAH build (read at scene upload; 0 = the built tree)
+  int uv_tables = 1;  // read at scene upload: image textures get the table that lets sphere hits find their texel without f64 acos / atan2 (0 = the formula)
   int probe_count = 0;  // probe_tree 3 / 4: count node visits / primitive tests (instrumented traversal) instead of running the render kernels' own
   unsigned long long probe_rays = 0;
   uint32_t* d_counts = nullptr;
@@ -1448,6 +1449,8 @@ int rt_set_option(rt_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "bvh_optimise") {
     if (value < 0 || value > 16) return fail(ctx, RT_E_INVALID_ARG, "bvh_optimise must be in 0..16");
     ctx->bvh_optimise = (int)value;
+  } else if (k == "uv_tables") {
+    ctx->uv_tables = value ? 1 : 0;
   } else if (k == "probe_count") {
     ctx->probe_count = value ? 1 : 0;
   } else if (k == "fused_tail4" || k == "fused_tail2") {
@@ -1873,12 +1876,60 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
   HIP_TRY(ctx, hipMemcpy(sc->d_prims, prims.data(), prims.size() * sizeof(Prim), hipMemcpyHostToDevice));
   HIP_TRY(ctx, rti::dev_malloc(&sc->d_mats, mats.size() * sizeof(Material)));
   HIP_TRY(ctx, hipMemcpy(sc->d_mats, mats.data(), mats.size() * sizeof(Material), hipMemcpyHostToDevice));
+  if (d->n_texel_bytes) {
+    // Behind the texels: per image size, the table that sphere_texel_checked (rt_device.h) verifies its f32 guess of the
+    // texel against — W + 1 unit vectors (cos b_i, sin b_i), b_i = 2 pi i / W - pi (the longitudes where the texel column
+    // changes), then H + 1 values cos(pi j / H) (the heights where the row changes); computed in long double.
+    std::vector<double> tables;
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> table_of;  // (W, H) -> offset in 32-bit words from the texel base
+    const uint64_t texel_words = ((d->n_texel_bytes + 15) & ~15ull) / 4;
+    for (Texture& t : texs) {
+      if (t.kind != RT_TEX_IMAGE || !t.width || !t.height || !ctx->uv_tables) continue;
+      if ((uint64_t)t.width + t.height > (1u << 20)) continue;  // (absurd sizes: the f64 formula serves)
+      const auto key = std::make_pair(t.width, t.height);
+      auto it = table_of.find(key);
+      if (it == table_of.end()) {
+        const uint64_t off = texel_words + tables.size() * 2;
+        if (off > 0xFFFFFFFFull) continue;
+        // (cos, sin) of (pi / 2) * m / n with the quarter turns taken out in integers: multiples of pi / 2 come out as
+        // exactly (+-1, 0) / (0, +-1), so a normal exactly ON an axis meets an exact boundary (inclusive below, like floor)
+        auto unit = [](int64_t m, int64_t n, double& c, double& sn) {
+          const long double half_pi = 1.57079632679489661923132169163975144L;
+          int64_t q = (2 * m + n) / (2 * n);
+          if ((2 * m + n) % (2 * n) < 0) q--;  // floor division
+          const int64_t r = m - q * n;           // |r| <= n / 2
+          const long double a = half_pi * (long double)r / (long double)n;
+          const long double cr = cosl(a), sr = sinl(a);
+          switch (((q % 4) + 4) % 4) {
+            case 0: c = (double)cr; sn = (double)sr; break;
+            case 1: c = (double)-sr; sn = (double)cr; break;
+            case 2: c = (double)-cr; sn = (double)-sr; break;
+            default: c = (double)sr; sn = (double)-cr; break;
+          }
+        };
+        for (uint32_t i = 0; i <= t.width; i++) {  // b_i = 2 pi i / W - pi = (pi / 2) * (4 i - 2 W) / W
+          double c, sn;
+          unit(4 * (int64_t)i - 2 * (int64_t)t.width, (int64_t)t.width, c, sn);
+          tables.push_back(c);
+          tables.push_back(sn + 0.0);  // (-0 -> +0: the seam's two entries are the same direction, exactly (-1, 0))
+        }
+        for (uint32_t j = 0; j <= t.height; j++) {  // cos(pi j / H) = cos((pi / 2) * 2 j / H)
+          double c, sn;
+          unit(2 * (int64_t)j, (int64_t)t.height, c, sn);
+          tables.push_back(c + 0.0);
+        }
+        if (tables.size() & 1) tables.push_back(0.0);  // the next table starts on 16 bytes
+        it = table_of.emplace(key, (uint32_t)off).first;
+      }
+      t.uvtab_off = it->second;
+    }
+    HIP_TRY(ctx, rti::dev_malloc(&sc->d_texels, texel_words * 4 + tables.size() * sizeof(double) + 16));
+    HIP_TRY(ctx, hipMemcpy(sc->d_texels, d->texels, d->n_texel_bytes, hipMemcpyHostToDevice));
+    if (!tables.empty())
+      HIP_TRY(ctx, hipMemcpy(sc->d_texels + texel_words, tables.data(), tables.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   HIP_TRY(ctx, rti::dev_malloc(&sc->d_texs, texs.size() * sizeof(Texture)));
   HIP_TRY(ctx, hipMemcpy(sc->d_texs, texs.data(), texs.size() * sizeof(Texture), hipMemcpyHostToDevice));
-  if (d->n_texel_bytes) {
-    HIP_TRY(ctx, rti::dev_malloc(&sc->d_texels, (d->n_texel_bytes + 3) & ~3ull));
-    HIP_TRY(ctx, hipMemcpy(sc->d_texels, d->texels, d->n_texel_bytes, hipMemcpyHostToDevice));
-  }
   if (sc->spheres_only) {
     std::vector<SphereRec> recs(prims.size());
     for (size_t i = 0; i < prims.size(); i++) {
