@@ -130,6 +130,26 @@ struct Hits {
 #define RT_F_TEX_ANY 7u
 
 // ----------------------------------------------------------------------------------------------- RNG
+// a ^ b ^ c in one instruction: gfx950's v_bitop3_b32 evaluates any three-input truth table (0x96 = odd parity); hipcc
+// emits two v_xor_b32.  `k` variant: the third operand from an SGPR (one scalar operand per VOP3 instruction).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#else
+  return a ^ b ^ c;
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t xor3k(uint32_t a, uint32_t b, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+#else
+  return a ^ b ^ k;
+#endif
+}
 // Philox4x32-10 (Salmon et al., SC'11).  generate_ray evaluates it once per path: counter = (pixel, sample, 0, 0), key = seed.
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1, uint32_t out[4]) {
@@ -145,7 +165,7 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   for (int r = 0; r < 10; r++) {
     uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    uint32_t n0 = xor3k(hi1, c1, k0), n1 = lo1, n2 = xor3k(hi0, c3, k1), n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += W0; k1 += W1;
   }
@@ -164,7 +184,7 @@ __device__ __forceinline__ uint32_t rng_next(PathRng& g) {
   uint32_t s1 = g.s1;
   const uint32_t r = rotl32(s0 * 0x9E3779BBu, 5) * 5u;
   s1 ^= s0;
-  g.s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9);
+  g.s0 = xor3(rotl32(s0, 26), s1, s1 << 9);
   g.s1 = rotl32(s1, 13);
   return r;
 }
@@ -1496,9 +1516,57 @@ __device__ __forceinline__ double noise_value(uint4 st) {
 // The jump is linear over GF(2), so the state splits into parts that depend on x only (2 values), on y only
 // (2 values) and on (y's sign, z) (4 values): 40 table lookups for the 8 corners instead of 128.
 // Corner k: x bit 0, z bit 1, y bit 2 (order of texture.rs:130-137).
+#ifndef RT_NOISE_INLINE
+#define RT_NOISE_INLINE 1
+#endif
+// The same with the row fetches in line (the compiler overlaps the 40 LDS reads instead of waiting after every four) and
+// the XOR trees in three-input steps: per state word 28 v_bitop3 / v_xor instead of 48 v_xor.
+template <class TabT>
+__device__ __forceinline__ u32x4 noise_rows(TabT table, uint32_t word, int row0) {  // the 4 rows the bytes of `word` select
+  const u32x4 a = table[(row0 + 0) * 256 + (word & 0xffu)], b = table[(row0 + 1) * 256 + ((word >> 8) & 0xffu)];
+  const u32x4 c = table[(row0 + 2) * 256 + ((word >> 16) & 0xffu)], d = table[(row0 + 3) * 256 + (word >> 24)];
+  return u32x4{xor3(a.x, b.x, c.x) ^ d.x, xor3(a.y, b.y, c.y) ^ d.y, xor3(a.z, b.z, c.z) ^ d.z, xor3(a.w, b.w, c.w) ^ d.w};
+}
+__device__ __forceinline__ double noise_value_words(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  // next_u64 = s0 + s1 with s0 = x | y << 32, s1 = z | w << 32 (random.rs:18-28); next_f64 = that / 2^64 (random.rs:30-32):
+  // hi * 2^-32 + lo * 2^-64 in one fma rounds once, exactly like the u64 -> f64 conversion followed by the exact scaling
+  const uint32_t lo = x + z;
+  const uint32_t hi = y + w + (lo < x ? 1u : 0u);
+  return __builtin_fma((double)hi, 0x1p-32, (double)lo * 0x1p-64);
+}
+template <class TabT>
+__device__ __forceinline__ void noise_corners_inline(TabT table, int32_t ix, int32_t iy, int32_t iz, double c[8]) {
+  u32x4 tx[2], ty[2], tz[4];
+#pragma unroll
+  for (int dx = 0; dx < 2; dx++) {
+    const int32_t cx = (int32_t)((uint32_t)ix + (uint32_t)dx);
+    const u32x4 a = noise_rows(table, (uint32_t)cx, 0), b = noise_rows(table, cx < 0 ? 0xffffffffu : 0u, 4);
+    tx[dx] = a ^ b;
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++) {
+    const int32_t cy = (int32_t)((uint32_t)iy + (uint32_t)dy);
+    ty[dy] = noise_rows(table, (uint32_t)cy, 8);
+#pragma unroll
+    for (int dz = 0; dz < 2; dz++) {
+      const uint32_t cz = (uint32_t)iz + (uint32_t)dz;
+      tz[dy * 2 + dz] = noise_rows(table, cz + (cy < 0 ? 0xffffffffu : 0u), 12);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int dx = k & 1, dz = (k >> 1) & 1, dy = (k >> 2) & 1;
+    const u32x4 &a = tx[dx], &b = ty[dy], &d = tz[dy * 2 + dz];
+    c[k] = noise_value_words(xor3(a.x, b.x, d.x), xor3(a.y, b.y, d.y), xor3(a.z, b.z, d.z), xor3(a.w, b.w, d.w));
+  }
+}
 template <class TabT>
 __device__ __forceinline__ void noise_corners_dev(TabT table, int32_t ix, int32_t iy, int32_t iz,
                                                   double c[8]) {
+  if constexpr (RT_NOISE_INLINE) {
+    noise_corners_inline(table, ix, iy, iz, c);
+    return;
+  }
   uint4 tx[2], ty[2], tz[4];
 #pragma unroll
   for (int dx = 0; dx < 2; dx++) {
