@@ -1560,10 +1560,12 @@ __device__ __forceinline__ void noise_corners_inline(TabT table, int32_t ix, int
     c[k] = noise_value_words(xor3(a.x, b.x, d.x), xor3(a.y, b.y, d.y), xor3(a.z, b.z, d.z), xor3(a.w, b.w, d.w));
   }
 }
-template <class TabT>
+// INLINE: the kernels whose only textures are checkers and noise (C3b); the general instances, where a noise lookup is
+// one shading path among many, keep the out-of-line rows and their registers.
+template <bool INLINE, class TabT>
 __device__ __forceinline__ void noise_corners_dev(TabT table, int32_t ix, int32_t iy, int32_t iz,
                                                   double c[8]) {
-  if constexpr (RT_NOISE_INLINE) {
+  if constexpr (RT_NOISE_INLINE && INLINE) {
     noise_corners_inline(table, ix, iy, iz, c);
     return;
   }
@@ -1645,6 +1647,22 @@ __device__ __forceinline__ bool sphere_texel_checked(d3 on, const double* __rest
   const double lo = b0.x * py - b0.y * px, hi = b1.x * py - b1.y * px;  // > 0: counter-clockwise of the boundary
   return lo >= 0. && hi < 0. && on.y <= c0 && on.y > c1;
 }
+#ifndef RT_UV_FORMULA_CALL
+#define RT_UV_FORMULA_CALL 1
+#endif
+// get_sphere_uv + ImageTexture::value's index arithmetic (the formulas themselves) as a function of the outward normal,
+// OUT OF LINE: the failed checks of sphere_texel_checked call it, so the f64 acos / atan2 code and its two dozen live
+// registers are not part of the shading code's register budget.  Returns i | j << 32.
+__device__ __noinline__ uint64_t sphere_texel_formula(double nx, double ny, double nz, uint32_t W, uint32_t H) {
+  double u, v;
+  sphere_uv(d3{nx, ny, nz}, u, v);
+  u = fmin(fmax(u, 0.0), 1.0);
+  v = 1.0 - fmin(fmax(v, 0.0), 1.0);
+  uint32_t i = (uint32_t)(u * (double)W), j = (uint32_t)(v * (double)H);
+  i = i > W - 1 ? W - 1 : i;  // deviation: clamp where the reference would panic
+  j = j > H - 1 ? H - 1 : j;
+  return (uint64_t)i | ((uint64_t)j << 32);
+}
 template <uint32_t F, class Acc>
 __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t ti, int32_t pi, const HitRec& h0, d3 o,
                                         d3 d, double time, double t) {
@@ -1667,22 +1685,33 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
     if ((F & RT_F_TEX_IMAGE) && kind == 2u) {  // texture.rs:79-93
       if (T.width == 0 || T.height == 0) return {0.f, 1.f, 1.f};
       uint32_t i = 0, j = 0;
-      bool have = false;
-      if (T.uvtab_off && !h0.uv_valid && (Acc::kSpheresOnly || acc.type(pi) <= 1u)) {
+      if (RT_UV_FORMULA_CALL && !h0.uv_valid && (Acc::kSpheresOnly || acc.type(pi) <= 1u)) {
         const HitRec h = make_hit(acc, pi, o, d, time, t, false);  // (the outward normal in f64, as the reference has it)
-        have = sphere_texel_checked(h.outward, reinterpret_cast<const double*>(sc.texels + T.uvtab_off), T.width, T.height, i, j);
-      }
-      if (!have) {
-        double u = h0.u, v = h0.v;
-        if (!h0.uv_valid) {
-          HitRec h = make_hit(acc, pi, o, d, time, t, true);
-          u = h.u; v = h.v;
+        bool have = false;
+        if (T.uvtab_off)
+          have = sphere_texel_checked(h.outward, reinterpret_cast<const double*>(sc.texels + T.uvtab_off), T.width, T.height, i, j);
+        if (!have) {  // ~1e-4 of the hits (or no table): out of line, so that its registers are not the branch's
+          const uint64_t ij = sphere_texel_formula(h.outward.x, h.outward.y, h.outward.z, T.width, T.height);
+          i = (uint32_t)ij; j = (uint32_t)(ij >> 32);
         }
-        u = fmin(fmax(u, 0.0), 1.0);
-        v = 1.0 - fmin(fmax(v, 0.0), 1.0);
-        i = (uint32_t)(u * (double)T.width); j = (uint32_t)(v * (double)T.height);
-        i = i > T.width - 1 ? T.width - 1 : i;  // deviation: clamp where the reference would panic
-        j = j > T.height - 1 ? T.height - 1 : j;
+      } else {
+        bool have = false;
+        if (T.uvtab_off && !h0.uv_valid && (Acc::kSpheresOnly || acc.type(pi) <= 1u)) {
+          const HitRec h = make_hit(acc, pi, o, d, time, t, false);
+          have = sphere_texel_checked(h.outward, reinterpret_cast<const double*>(sc.texels + T.uvtab_off), T.width, T.height, i, j);
+        }
+        if (!have) {
+          double u = h0.u, v = h0.v;
+          if (!h0.uv_valid) {
+            HitRec h = make_hit(acc, pi, o, d, time, t, true);
+            u = h.u; v = h.v;
+          }
+          u = fmin(fmax(u, 0.0), 1.0);
+          v = 1.0 - fmin(fmax(v, 0.0), 1.0);
+          i = (uint32_t)(u * (double)T.width); j = (uint32_t)(v * (double)T.height);
+          i = i > T.width - 1 ? T.width - 1 : i;  // deviation: clamp where the reference would panic
+          j = j > T.height - 1 ? T.height - 1 : j;
+        }
       }
       uint32_t px = sc.texels[T.texel_off + j * T.width + i];
       const float k = 1.0f / 255.0f;
@@ -1694,7 +1723,7 @@ __device__ __forceinline__ f3 tex_value(const Scene& sc, const Acc& acc, int32_t
       double fx = rem_euclid1(x), fy = rem_euclid1(y), fz = rem_euclid1(z);
       double xb = fx * fx * (3.0 - 2.0 * fx), yb = fy * fy * (3.0 - 2.0 * fy), zb = fz * fz * (3.0 - 2.0 * fz);
       double c[8];
-      noise_corners_dev(acc.noise_table(sc), ix, iy, iz, c);
+      noise_corners_dev<(F & ~(RT_F_TEX_CHECKER | RT_F_TEX_NOISE)) == 0u>(acc.noise_table(sc), ix, iy, iz, c);
       auto lerp = [](double a, double b, double w) { return (1.0 - w) * a + w * b; };  // color.rs:62-64
       double m00 = lerp(c[0], c[1], xb), m01 = lerp(c[2], c[3], xb);
       double m10 = lerp(c[4], c[5], xb), m11 = lerp(c[6], c[7], xb);

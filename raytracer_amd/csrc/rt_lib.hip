@@ -1885,7 +1885,7 @@ static int scene_upload_impl(rt_ctx* ctx, const rt_scene_desc* d, rt_scene* sc) 
     const uint64_t texel_words = ((d->n_texel_bytes + 15) & ~15ull) / 4;
     for (Texture& t : texs) {
       if (t.kind != RT_TEX_IMAGE || !t.width || !t.height || !ctx->uv_tables) continue;
-      if ((uint64_t)t.width + t.height > (1u << 20)) continue;  // (absurd sizes: the f64 formula serves)
+      if ((uint64_t)t.width + t.height > (1u << 20)) continue;  // (absurd sizes: the f64 formulas serve)
       const auto key = std::make_pair(t.width, t.height);
       auto it = table_of.find(key);
       if (it == table_of.end()) {
