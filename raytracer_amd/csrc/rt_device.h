@@ -190,7 +190,8 @@ __device__ __forceinline__ uint32_t rng_next(PathRng& g) {
 }
 
 __device__ __forceinline__ float u01f(uint32_t x) { return (float)(x >> 8) * 5.9604645e-8f + 2.9802322e-8f; }  // (0,1)
-__device__ __forceinline__ double u01d(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
+// (x + 0.5) * 2^-32 as one fma: both forms are exact (x < 2^32), so the bits are the same
+__device__ __forceinline__ double u01d(uint32_t x) { return __builtin_fma((double)x, 2.3283064365386963e-10, 1.1641532182693481e-10); }
 
 // ----------------------------------------------------------------------------------------------- math
 struct d3 { double x, y, z; };
