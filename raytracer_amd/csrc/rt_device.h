@@ -1541,8 +1541,13 @@ __device__ __forceinline__ void noise_corners_inline(TabT table, int32_t ix, int
 #pragma unroll
   for (int dx = 0; dx < 2; dx++) {
     const int32_t cx = (int32_t)((uint32_t)ix + (uint32_t)dx);
-    const u32x4 a = noise_rows(table, (uint32_t)cx, 0), b = noise_rows(table, cx < 0 ? 0xffffffffu : 0u, 4);
-    tx[dx] = a ^ b;
+    // the coordinate's four bytes, and its sign extension: ONE row (the host folds positions 4..7, rt_init; value 0 -> 0)
+    const uint32_t w = (uint32_t)cx;
+    const u32x4 a = table[0 * 256 + (w & 0xffu)], b = table[1 * 256 + ((w >> 8) & 0xffu)];
+    const u32x4 c = table[2 * 256 + ((w >> 16) & 0xffu)], e = table[3 * 256 + (w >> 24)];
+    const u32x4 g = table[4 * 256 + (cx < 0 ? 255u : 0u)];
+    tx[dx] = u32x4{xor3(xor3(a.x, b.x, c.x), e.x, g.x), xor3(xor3(a.y, b.y, c.y), e.y, g.y),
+                   xor3(xor3(a.z, b.z, c.z), e.z, g.z), xor3(xor3(a.w, b.w, c.w), e.w, g.w)};
   }
 #pragma unroll
   for (int dy = 0; dy < 2; dy++) {

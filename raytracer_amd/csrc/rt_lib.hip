@@ -1373,6 +1373,18 @@ int rt_init(int device_id, rt_ctx** out) {
       uint32_t* t = &tab[(size_t)(i * 256 + v) * 4];
       t[0] = (uint32_t)s[0]; t[1] = (uint32_t)(s[0] >> 32); t[2] = (uint32_t)s[1]; t[3] = (uint32_t)(s[1] >> 32);
     }
+  // Byte positions 4..7 hold the sign extension of a lattice coordinate (texture.rs:149: `x as u64`): all 0x00 or all
+  // 0xff, never anything else.  Their four 0xff entries are folded into ONE (position 4's; the other three become zero),
+  // so the sign costs the device one row fetch instead of four (noise_corners_inline) and the row-by-row form
+  // (noise_jump_part) still gets the same XOR.
+  for (int k = 0; k < 4; k++) {
+    uint32_t& folded = tab[(size_t)(4 * 256 + 255) * 4 + k];
+    for (int i = 5; i < 8; i++) {
+      uint32_t& t = tab[(size_t)(i * 256 + 255) * 4 + k];
+      folded ^= t;
+      t = 0;
+    }
+  }
   if ((e = rti::dev_malloc(&ctx->d_noise_table, tab.size() * 4)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemcpy(ctx->d_noise_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
     return bail("hipMemcpy", e);
