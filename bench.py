@@ -269,14 +269,37 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
-    if args.rehearse:
+    if args.rehearse or os.environ.get("BENCH_SAME_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    # How partial frames reach rank 0: RCCL over xGMI, on a process group of its own.  The default group is gloo (timing
+    # exchange, barriers, and the channel over which the ranks AGREE on what follows): the RCCL group is created and
+    # probed with one all-reduce inside a try on every rank, and if that fails anywhere all ranks stage their frames
+    # through host memory instead — a slower line that says "reduce": "host" rather than no line at all.
+    # (--rehearse: host memory from the start, every rank on GPU 0.  BENCH_SAME_GPU=1: test hook, the real path with every
+    # rank on GPU 0, where RCCL must refuse and the fallback must carry the run.)
+    rccl_group = None
+    use_host_reduce = bool(args.rehearse)
+    reduce_note = "gloo through host memory (rehearsal)" if args.rehearse else "rccl"
     if world > 1:
-        if args.rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
+        if not args.rehearse:
+            ok, why = 1, ""
+            try:
+                rccl_group = dist.new_group(backend="nccl")
+                probe = torch.ones(1, dtype=torch.float32, device="cuda")
+                dist.all_reduce(probe, group=rccl_group)
+                torch.cuda.synchronize()
+                ok = 1 if abs(float(probe.item()) - world) < 0.5 else 0
+                why = "" if ok else "the probe all-reduce returned a wrong sum"
+            except Exception as exc:  # noqa: BLE001 - whatever RCCL raises, the bench goes on through host memory
+                ok, why = 0, f"{type(exc).__name__}: {exc}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                use_host_reduce = True
+                reduce_note = "host memory (gloo): RCCL failed on some rank" + (f" - here: {why[:200]}" if why else "")
+                print(f"[bench rank {rank}] RCCL unavailable, reducing through host memory. {why[:300]}", file=sys.stderr)
 
     import numpy as np
     import raytracer_amd as ra
@@ -305,13 +328,19 @@ def main():
     torch.cuda.synchronize()
     first_frame_ms = (time.perf_counter() - t0) * 1e3
 
-    def reduce_to_rank0():
-        if world > 1 and args.rehearse:
-            h = d_sum.cpu()
+    def reduce_sum(t):
+        # partial frame of every rank -> their sum on rank 0, in place
+        if world == 1:
+            return
+        if use_host_reduce:
+            h = t.cpu()
             dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-            d_sum.copy_(h)
-        elif world > 1:
-            dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=rccl_group)
+
+    def reduce_to_rank0():
+        reduce_sum(d_sum)
 
     def resolve(spp_total):
         if rank == 0:
@@ -334,7 +363,8 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            torch.cuda.synchronize()  # this rank's launches and reduces are done ...
+            dist.barrier()            # ... and so are everybody's (gloo)
         torch.cuda.synchronize()
 
     def timed(step, n_steps, n_warm):
@@ -347,7 +377,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
+            t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -392,12 +422,7 @@ def main():
             ra.render_batch_device(rig.dev, rig.cam, ptrs, [(seed0 + 1000 + i * B + k) & 0xFFFFFFFFFFFFFFFF for k in range(B)],
                                    [b_] * B, sample_end=e_, sample_stride=s_, stream=stream)
             for o in outs:
-                if world > 1 and args.rehearse:
-                    h = o.cpu()
-                    dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-                    o.copy_(h)
-                elif world > 1:
-                    dist.reduce(o, dst=0, op=dist.ReduceOp.SUM)
+                reduce_sum(o)
                 if rank == 0:
                     ctx.check(ctx.L.rt_resolve_device(ctx.h, o.data_ptr(), W, H, rig.spp, 2.2, None, d_u8.data_ptr(), stream))
 
@@ -451,12 +476,7 @@ def main():
                 b, e, st = mg.sample_slice(rank, world, r3.spp)
                 r3.dev.render_device(r3.cam, d3.data_ptr(), seed=(seed0 + i) & 0xFFFFFFFFFFFFFFFF, sample_begin=b, sample_end=e,
                                      sample_stride=st, stream=stream)
-                if world > 1 and args.rehearse:
-                    h = d3.cpu()
-                    dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-                    d3.copy_(h)
-                elif world > 1:
-                    dist.reduce(d3, dst=0, op=dist.ReduceOp.SUM)
+                reduce_sum(d3)
                 if rank == 0:
                     ctx.check(ctx.L.rt_resolve_device(ctx.h, d3.data_ptr(), r3.W, r3.H, r3.spp, 2.2, None, u3.data_ptr(), stream))
 
@@ -478,13 +498,15 @@ def main():
             "data": f"synthetic (scene builder {rig.scene_name}, fixed seeds)" + (" REHEARSAL, not a measurement" if args.rehearse else ""),
             "config": {"workload": rig.label(), "samples_per_step": frame_samples,
                        "spp_per_gpu": [mg.samples_in_slice(*mg.sample_slice(r, world, rig.spp)) for r in range(world)],
-                       "parallelism": (f"sample indices split x{world} (residue classes) + one RCCL reduce of "
-                                       f"{W * H * 12} B per rank") if world > 1 else "single GPU"},
+                       "parallelism": (f"sample indices split x{world} (residue classes) + one reduce of "
+                                       f"{W * H * 12} B per rank to rank 0 ({reduce_note})") if world > 1 else "single GPU"},
             "roofline": roofline_block(args.workload, rig.wl, my_samples, k_ms, stats, own, frame_samples),
         }
         out["roofline"]["note"] = ("rank 0's launch: %d of the frame's %d samples" % (my_samples, frame_samples)) if world > 1 else \
             "one launch = the whole frame"
         out.update(extra)
+        if world > 1:
+            out["reduce"] = "host" if use_host_reduce else "rccl"
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N=1 only (the other ranks would idle on it)
             out["cpu_baseline"] = cpu_baseline(rig.scene_name, rig.width_req, rig.depth, rig.texels)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
@@ -557,7 +579,7 @@ def main():
                 del acc5, p5, d16, r5, r16
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
